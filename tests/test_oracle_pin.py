@@ -1,0 +1,70 @@
+"""Pins the CPU oracle to the reference's own outputs.
+
+The reference has no tests; the known answers below were
+recorded from the reference itself at survey time: LCG
+input seed 12345 over 40 blocks of 262144 bytes, FNV-style hash over the int16
+PCM, plus the hex-float tap/scalar constants.  Bit-exact match required.
+"""
+import numpy as np
+import pytest
+
+from oracle import OracleStream, hash16
+
+BL = 262144
+
+KNOWN = {
+    # name: (config, total int16, hash, first block lens)
+    "stereo_300k": (dict(rate_in=300000, rate_out2=48000, mode=2), 209714, 0xC3E7EDA4BD16DFE1, (5242, 5242, 5244)),
+    "mono_300k": (dict(rate_in=300000, rate_out2=48000, mode=1), 104857, 0x2109FE431B558355, None),
+    "nfm_25k": (dict(rate_in=25000, rate_out2=12500, mode=1), 327680, 0x3E6F57574F3156AA, None),
+    "stereo_240k": (dict(rate_in=240000, rate_out2=48000, mode=2), 262144, 0x8E0413ED2BF00E75, None),
+    "stereo_192k": (dict(rate_in=192000, rate_out2=48000, mode=2), 327680, 0x6E145D091E77DBC9, None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN))
+def test_known_answer_hash(name, lcg40):
+    cfg, n_exp, h_exp, lens_exp = KNOWN[name]
+    s = OracleStream(**cfg)
+    pcm, lens = s.run(lcg40, BL)
+    assert pcm.size == n_exp
+    assert hash16(pcm) == h_exp
+    if lens_exp:
+        assert tuple(lens[:3]) == lens_exp
+
+
+def test_tap_constants():
+    fb_hex = ["-0x1.5014bap-12", "-0x1.1de03ep-10", "-0x1.2d5db6p-9", "-0x1.09e52ep-8", "-0x1.8ce0e4p-8",
+              "-0x1.ea157cp-8", "-0x1.cfe07ep-8", "-0x1.c264cp-9", "0x1.31a9cap-8", "0x1.241a5ap-6",
+              "0x1.24baf8p-5", "0x1.d2ec56p-5", "0x1.44cfdp-4", "0x1.989034p-4", "0x1.d8b6a4p-4",
+              "0x1.fb840ep-4"]
+    s = OracleStream(rate_in=300000, rate_out2=48000, mode=2)
+    t = s.taps()
+    assert [float(x) for x in t["fb"]] == [float.fromhex(h) for h in fb_hex]
+    assert t["swf"] == float.fromhex("0x1.8cd0e4p-2")
+    assert t["cwf"] == float.fromhex("0x1.d7fe72p-1")
+    assert float(np.float32(s.cfg.deemph_lambda)) == float.fromhex("0x1.5187fcp-1")
+    assert float(np.float32(0.4) * np.float32(32768.0)) == float.fromhex("0x1.99999ap+13")
+
+
+def test_block_split_invariance(lcg40):
+    """State carry: 8 blocks in one run == the same bytes fed block by block."""
+    a = OracleStream(rate_in=300000, rate_out2=48000, mode=2)
+    pa, _ = a.run(lcg40[: 8 * BL], BL)
+    b = OracleStream(rate_in=300000, rate_out2=48000, mode=2)
+    pb = np.concatenate([b.block(lcg40[i * BL:(i + 1) * BL]) for i in range(8)])
+    assert np.array_equal(pa, pb)
+
+
+def test_q1_block_is_exercised(lcg40):
+    """Block 2 at 300k->48k starts with an emit: the
+    resampler output written at index 1 replaces discriminator sample 1."""
+    s = OracleStream(rate_in=300000, rate_out2=48000, mode=2)
+    for b in range(2):
+        s.block(lcg40[b * BL:(b + 1) * BL])
+    st = s.get_state()
+    assert st.acc + 48000 >= 300000          # emit on the block's first sample
+    _, tr = s.block(lcg40[2 * BL:3 * BL], trace=True)
+    hist = s.get_state()
+    assert tr["mpx"].size in (5242, 5244)
+    assert hist.size == 90
