@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the IQ -> PCM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the fused kernel over one resident batch of synthetic u8
+IQ: `--streams` independent 2.4 Msps wide-FM stereo streams per GPU (default
+256, BASELINE.json configs[2]) x `--blocks` reference blocks of 262144 bytes.
+Streams shard across GPUs with no data-path collective (weak scaling); RCCL is
+used only to gather the per-rank counters.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BLOCK_LEN = 262144            # MAXIMUM_BUF_LENGTH, one reference block of u8 IQ
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
+    ap.add_argument("--math", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--mode", choices=["stereo", "mono"], default="stereo")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_kw, seconds):
+    """The oracle (a bit-exact CPU port of the reference path) on this host's cores:
+    one independent stream per thread, bounded sample of the same workload."""
+    from oracle import OracleStream, lcg_bytes
+    n_thr = os.cpu_count() or 1
+    nb = 8
+    iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
+    streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
+    streams[0].run(iqs[0], BLOCK_LEN)                      # page in / warm up
+    done = [0] * n_thr
+    stop = time.perf_counter() + seconds
+
+    def work(t):
+        while time.perf_counter() < stop:
+            streams[t].run(iqs[t], BLOCK_LEN)
+            done[t] += nb * BLOCK_LEN // 2
+
+    t0 = time.perf_counter()
+    thr = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    [x.start() for x in thr]
+    [x.join() for x in thr]
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(sum(done) / dt / 1e6, 2),
+        "unit": "Msamples/s",
+        "cores": n_thr,
+        "kind": "port",
+        "sample": "%d threads x independent streams, %d-block runs of LCG u8 IQ for %.0f s "
+                  "(oracle/fm_oracle.c, -O3 -ffp-contract=off)" % (n_thr, nb, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import rtl_fm_player_amd as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    stereo = args.mode == "stereo"
+    cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
+    math = R.MATH_FAST if args.math == "fast" else R.MATH_EXACT
+    cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math, **cfg_kw)
+    S, B = args.streams, args.blocks
+    batch = R.BatchDemod(cfg, S, device=local)
+
+    # synthetic IQ resident in HBM: uniform random bytes, per-rank seed
+    g = torch.Generator(device=dev)
+    g.manual_seed(12345 + rank)
+    iq = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=g)
+    pcm = torch.zeros((S, B, batch.pcm_stride), dtype=torch.int16, device=dev)
+    lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        batch.run_device(iq, B, pcm, lens, hip_stream=stream.cuda_stream)
+
+    # ---- parity gate (stream 0 and one other stream against the oracle) ----
+    parity = None
+    if not args.no_check:
+        from oracle import OracleStream
+        step()
+        torch.cuda.synchronize(dev)
+        worst = 0
+        for s in sorted({0, (7 * rank + S // 3) % S}):
+            want, wl = OracleStream(**cfg_kw).run(iq[s].cpu().numpy().reshape(-1), BLOCK_LEN)
+            l = lens[s].cpu().numpy()
+            assert np.array_equal(l, wl), "result_len mismatch on stream %d" % s
+            p = pcm[s].cpu().numpy()
+            got = np.concatenate([p[b, :l[b]] for b in range(B)])
+            worst = max(worst, int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()))
+        tol = 0 if args.math == "exact" else 1
+        assert worst <= tol, "PCM differs from the CPU oracle by %d LSB (tolerance %d)" % (worst, tol)
+        parity = {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": 2}
+        batch.reset()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    samples_per_step = S * B * (BLOCK_LEN // 2)
+    pcm_bytes = int(lens.sum().item()) * 2
+    algo_bytes = S * B * BLOCK_LEN + pcm_bytes                 # u8 IQ in + s16 PCM out, per launch
+
+    # ---- gather the per-rank counters over RCCL (no data-path collective) ----
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([samples_per_step * args.steps, int(kernel_ms * 1e6), int(pcm.view(torch.int16).sum().item())],
+                       dtype=torch.int64, device=dev)
+    if dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        total_samples = int(sum(int(c[0]) for c in allc))
+    else:
+        total_samples = int(cnt[0])
+    elapsed = float(el.item())
+
+    if rank == 0:
+        value = total_samples / elapsed / 1e6
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "IQ Msamples/s through full_demod",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d concurrent 2.4 Msps %s WBFM streams per GPU x %d blocks of %d B u8 IQ "
+                            "(rate_in 300k -> 48k PCM), IQ resident in HBM" % (S, args.mode, B, BLOCK_LEN),
+                "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
+                "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "bytes_per_sample": round(algo_bytes / samples_per_step, 4),
+            },
+        }
+        if parity:
+            out["parity"] = parity
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds)
+        elif not args.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

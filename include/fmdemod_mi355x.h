@@ -1,0 +1,269 @@
+/*
+ * fmdemod_mi355x.h - C ABI of the MI355X-native FM demodulation path.
+ *
+ * Drop-in boundary for the IQ -> PCM hot path of rtl_fm_player
+ * (rotate_90_u8_f32 + full_demod, reference src/rtl_fm_player.c:206-226,
+ * :758-788).  Plain C, plain pointers and sizes; no HIP or torch types appear
+ * in any signature.  Everything here is exported by libfmdemod_mi355x.so
+ * (rtl_fm_player_amd/csrc).  The library runs every stage on the GPU with
+ * hand-written gfx950 kernels; there is no CPU fallback and every entry point
+ * fails (status < 0, or abort() for the void reference-shaped calls) when no
+ * HIP device is usable.
+ *
+ * Three groups of entry points:
+ *   1. the reference's own operator surface (same names, same struct layout)
+ *      so rtl_fm_player.c can link against this library instead of its own
+ *      definitions;
+ *   2. a batch API (many independent streams x many blocks per launch) which
+ *      is what the bench and the parity tests drive;
+ *   3. an rtlsdr_read_async_cb_t-compatible ingest callback feeding a
+ *      per-stream pinned staging ring.
+ */
+#ifndef FMDEMOD_MI355X_H
+#define FMDEMOD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * 1. Reference-shaped surface
+ * ------------------------------------------------------------------------
+ * Layout-compatible restatement of struct lp_real / struct demod_state
+ * (reference include/rtl_fm_player.h:95-110, :127-175; x86-64 glibc).  The
+ * reference header cannot be included from a second translation unit (it
+ * defines globals), so the layout is restated here and checked with static
+ * assertions in csrc/fmd_host.c against the offsets recorded in SURVEY.md
+ * section 8a (row a15).  Define FMD_NO_REFERENCE_TYPES before including this
+ * header from a TU that already has the reference's own definitions.
+ */
+#define FMD_DEFAULT_BUF_LENGTH (1 * 16384)                 /* include/rtl_fm_player.h:31 */
+#define FMD_MAXIMUM_OVERSAMPLE 16                          /* :32 */
+#define FMD_MAXIMUM_BUF_LENGTH (FMD_MAXIMUM_OVERSAMPLE * FMD_DEFAULT_BUF_LENGTH) /* :33 */
+
+#ifndef FMD_NO_REFERENCE_TYPES
+#include <pthread.h>
+
+struct output_state;
+
+struct lp_real {          /* include/rtl_fm_player.h:95-110 */
+  float *br;              /* ring of discriminator samples                */
+  float *bm;              /* ring of L+R low-pass outputs                 */
+  float *bs;              /* ring of demodulated L-R samples              */
+  float *fm;              /* half of the symmetric 0..16 kHz low-pass     */
+  float *fp;              /* half of the 18..20 kHz pilot band-pass       */
+  float *fs;              /* half of the 21..55 kHz L-R band-pass         */
+  float swf;              /* sin(2 pi 19000 / rate_in)                    */
+  float cwf;              /* cos(2 pi 19000 / rate_in)                    */
+  float pp;               /* previous pilot band-pass output              */
+  int pos;                /* ring write index                             */
+  int size;               /* taps (90 stereo, 128 mono)                   */
+  int rsize;              /* size / 2                                     */
+  int mode;               /* 0 drop, 1 mono, 2 stereo                     */
+};
+
+struct demod_state {      /* include/rtl_fm_player.h:127-175 */
+  int exit_flag;
+  pthread_t thread;
+  uint8_t buf[FMD_MAXIMUM_BUF_LENGTH];
+  uint32_t buf_len;
+  int16_t lowpassed[FMD_MAXIMUM_BUF_LENGTH << 1];
+  int lp_len;
+  float lowpass_tb[48];
+  int16_t lp_i_hist[10][6];
+  int16_t lp_q_hist[10][6];
+  int16_t result[FMD_MAXIMUM_BUF_LENGTH];
+  int result_len;
+  int16_t droop_i_hist[9];
+  int16_t droop_q_hist[9];
+  int offset_tuning;
+  int rate_in;
+  int rate_out;
+  int rate_out2;
+  int now_r, now_j;
+  int pre_r, pre_j;
+  float pre_r_f32, pre_j_f32;
+  int prev_index;
+  int downsample;
+  int post_downsample;
+  int output_scale;
+  int squelch_level, conseq_squelch, squelch_hits, terminate_on_squelch;
+  int downsample_passes;
+  int comp_fir_size;
+  int custom_atan;
+  double deemph;
+  int deemph_a;
+  int deemph_l;
+  int deemph_r;
+  float deemph_l_f32;
+  float deemph_r_f32;
+  float deemph_lambda;
+  float volume;
+  int now_lpr;
+  int prev_lpr_index;
+  struct lp_real lpr;
+  pthread_rwlock_t rw;
+  pthread_cond_t ready;
+  pthread_mutex_t ready_m;
+  struct output_state *output_target;
+};
+
+/* Same names, arguments and calling protocol as the reference:
+ *   fill d->buf / d->buf_len, call rotate_90_u8_f32(d) (or u8_f32(d)), then
+ *   full_demod(d), then read d->result_len int16 values from d->result
+ *   (src/rtl_fm_player.c:870-889, :904-908).
+ * rotate_90_u8_f32 / u8_f32 only record which conversion the next full_demod
+ * applies (and set lp_len like the reference); full_demod uploads d->buf,
+ * runs the whole chain on the GPU, downloads the PCM and mirrors every
+ * mutable state field back into *d (lowpass_tb, pre_*_f32, lpr rings/pos/pp,
+ * prev_lpr_index, deemph_*_f32), so CPU and GPU calls can be interleaved on
+ * one struct.  They return void like the originals; an unusable device or an
+ * unsupported configuration aborts with a message on stderr. */
+void init_u8_f32_table(void);                       /* src/rtl_fm_player.c:195 */
+void init_lp_f32(void);                             /* :241 */
+void init_lp_real_f32(struct demod_state *fm);      /* :413 */
+void deinit_lp_real_f32(struct demod_state *fm);    /* :455 */
+void demod_init(struct demod_state *s);             /* :1156 */
+void rotate_90_u8_f32(struct demod_state *d);       /* :206 */
+void u8_f32(struct demod_state *d);                 /* :228 */
+void full_demod(struct demod_state *d);             /* :758 */
+/* Additive: release the device resources full_demod attached to *d. */
+void fmd_demod_release(struct demod_state *d);
+#endif /* FMD_NO_REFERENCE_TYPES */
+
+/* ------------------------------------------------------------------------
+ * 2. Batch API: n_streams independent demodulators, many blocks per launch
+ * ------------------------------------------------------------------------ */
+
+/* status codes (0 ok, < 0 error) */
+#define FMD_OK 0
+#define FMD_E_ARG (-1)          /* bad argument                              */
+#define FMD_E_UNSUPPORTED (-2)  /* configuration outside the supported range */
+#define FMD_E_NOMEM (-3)
+#define FMD_E_HIP (-4)          /* HIP runtime error (see fmd_last_error)    */
+#define FMD_E_NODEVICE (-5)     /* no usable gfx950 device                   */
+#define FMD_E_STATE (-6)        /* call sequence error                       */
+
+/* arithmetic contract */
+#define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
+#define FMD_MATH_FAST 1   /* fused multiply-add, same summation order: PCM within +-1 LSB */
+
+typedef struct fmd_config {
+  int32_t rate_in;        /* demod_state.rate_in                               */
+  int32_t rate_out;       /* demod_state.rate_out  (resampler "fast")          */
+  int32_t rate_out2;      /* demod_state.rate_out2 (resampler "slow"), <=0 off */
+  int32_t mode;           /* lpr.mode 0/1/2                                    */
+  int32_t size;           /* lpr.size (even, <= 256)                           */
+  int32_t deemph;         /* nonzero: de-emphasis on                           */
+  int32_t offset_tuning;  /* nonzero: no fs/4 rotation (u8_f32 path)           */
+  float deemph_lambda;    /* demod_state.deemph_lambda                         */
+  float volume;           /* demod_state.volume                                */
+  int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
+                          /* multiple of 16, >= 64                             */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST                    */
+} fmd_config;
+
+/* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /
+ * init_lp_real_f32 do (host libm).  A caller may override them (tests hand
+ * the device path the very tables the oracle used). */
+typedef struct fmd_taps {
+  float fb[16];
+  float fm[128], fp[128], fs[128];
+  float swf, cwf;
+} fmd_taps;
+
+/* Carried state of one stream, linear oldest -> newest (mirrors the mutable
+ * fields of struct demod_state / struct lp_real). */
+typedef struct fmd_stream_state {
+  float tb[48];
+  float pre_r, pre_j;
+  float pp;
+  float deemph_l, deemph_r;
+  int32_t acc;            /* prev_lpr_index */
+  int32_t reserved[2];
+  float br[256], bm[256], bs[256];   /* last `size` values, oldest first, at [0..size) */
+} fmd_stream_state;
+
+/* Optional stage taps for debugging / parity tests: device pointers or NULL.
+ * Shapes per stream and block, M = block_len / 16:
+ *   y [2*M] f32, v [M] f32 (before the Q1 overwrite), mpx [M] f32 (resampler
+ *   output before de-emphasis, result_len entries used). */
+typedef struct fmd_debug_taps {
+  void *y, *v, *mpx;
+} fmd_debug_taps;
+
+typedef struct fmd_batch fmd_batch;
+
+int fmd_design_taps(const fmd_config *cfg, fmd_taps *out);
+float fmd_deemph_lambda(int output_rate, double tau);   /* src/rtl_fm_player.c:1577 */
+
+/* device < 0: current device.  taps == NULL: fmd_design_taps(cfg). */
+int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *taps,
+                     int n_streams, int device);
+void fmd_batch_destroy(fmd_batch *b);
+
+/* int16 slots per (stream, block) in the PCM buffer (multiple of 8). */
+int fmd_batch_pcm_stride(const fmd_batch *b);
+int fmd_batch_n_streams(const fmd_batch *b);
+
+/* Device-resident run.  Layouts (all device pointers):
+ *   d_iq   u8  [n_streams][n_blocks][block_len]
+ *   d_pcm  s16 [n_streams][n_blocks][pcm_stride]
+ *   d_lens i32 [n_streams][n_blocks]          (result_len of each block)
+ * hip_stream: a hipStream_t passed as void* (NULL = the batch's own stream).
+ * Asynchronous; state advances by n_blocks blocks per stream. */
+int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
+                         void *d_lens, void *hip_stream);
+int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
+                               void *d_lens, void *hip_stream, const fmd_debug_taps *dbg);
+int fmd_batch_sync(fmd_batch *b);
+
+/* Host-buffer convenience (H2D, run, D2H, sync); same layouts in host memory. */
+int fmd_batch_run_host(fmd_batch *b, const uint8_t *iq, int n_blocks, int16_t *pcm,
+                       int32_t *lens);
+
+/* Per-stream carried state (synchronises first). */
+int fmd_batch_get_state(fmd_batch *b, int stream, fmd_stream_state *out);
+int fmd_batch_set_state(fmd_batch *b, int stream, const fmd_stream_state *in);
+int fmd_batch_reset(fmd_batch *b);
+
+/* Duration of the most recent fmd_batch_run_device kernel, measured with HIP
+ * events recorded on the stream the kernel was launched on (synchronises). */
+int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms);
+/* Name of the dominant kernel (as rocprofv3 reports it) for this batch. */
+const char *fmd_batch_kernel_name(const fmd_batch *b);
+
+const char *fmd_last_error(void);
+int fmd_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * 3. Ingest: rtlsdr_read_async callback -> pinned staging ring -> batch
+ * ------------------------------------------------------------------------
+ * fmd_ingest_callback has the exact rtlsdr_read_async_cb_t signature
+ * (reference include/rtl-sdr.h:340) and the contract of rtlsdr_callback
+ * (src/rtl_fm_player.c:790-837): it copies `len` bytes before returning,
+ * never blocks on the GPU, and on overflow keeps the newest data and counts
+ * the drop.  ctx is an fmd_ingest* bound to one stream of a batch. */
+typedef struct fmd_ingest fmd_ingest;
+typedef void (*fmd_read_async_cb_t)(unsigned char *buf, uint32_t len, void *ctx);
+
+int fmd_ingest_create(fmd_ingest **out, fmd_batch *b, int stream, uint32_t ring_bytes);
+void fmd_ingest_destroy(fmd_ingest *g);
+void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx);
+/* Bytes currently buffered / dropped so far. */
+uint32_t fmd_ingest_buffered(const fmd_ingest *g);
+uint64_t fmd_ingest_dropped(const fmd_ingest *g);
+/* Mute the first n bytes of the next callback buffer (retune, :805-810). */
+void fmd_ingest_mute(fmd_ingest *g, int n_bytes);
+/* Demodulate whole blocks that every bound stream has buffered: returns the
+ * number of blocks processed per stream (>= 0) or an error.  pcm/lens as in
+ * fmd_batch_run_host, for max_blocks blocks. */
+int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMDEMOD_MI355X_H */

@@ -1,0 +1,696 @@
+/*
+ * fmd_host.c - C host layer of libfmdemod_mi355x.so.
+ *
+ * Plain C above the HIP runtime's C API: configuration and filter design,
+ * device buffers and carried state, the batch API, the reference-shaped
+ * entry points (same names / struct layout as rtl_fm_player.c) and the
+ * rtlsdr_read_async-compatible ingest ring.  All arithmetic of the hot path
+ * runs in the kernels of fmd_kernels.hip; nothing here computes a sample.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "fmd_internal.h"
+
+/* ---- layout of the reference structs ---- */
+_Static_assert(offsetof(struct demod_state, buf) == 16, "demod_state.buf");
+_Static_assert(offsetof(struct demod_state, buf_len) == 262160, "demod_state.buf_len");
+_Static_assert(offsetof(struct demod_state, lowpassed) == 262164, "demod_state.lowpassed");
+_Static_assert(offsetof(struct demod_state, lp_len) == 1310740, "demod_state.lp_len");
+_Static_assert(offsetof(struct demod_state, lowpass_tb) == 1310744, "demod_state.lowpass_tb");
+_Static_assert(offsetof(struct demod_state, result) == 1311176, "demod_state.result");
+_Static_assert(offsetof(struct demod_state, result_len) == 1835464, "demod_state.result_len");
+_Static_assert(offsetof(struct demod_state, rate_in) == 1835508, "demod_state.rate_in");
+_Static_assert(offsetof(struct demod_state, rate_out) == 1835512, "demod_state.rate_out");
+_Static_assert(offsetof(struct demod_state, rate_out2) == 1835516, "demod_state.rate_out2");
+_Static_assert(offsetof(struct demod_state, pre_r_f32) == 1835536, "demod_state.pre_r_f32");
+_Static_assert(offsetof(struct demod_state, deemph) == 1835592, "demod_state.deemph");
+_Static_assert(offsetof(struct demod_state, deemph_l_f32) == 1835612, "demod_state.deemph_l_f32");
+_Static_assert(offsetof(struct demod_state, deemph_lambda) == 1835620, "demod_state.deemph_lambda");
+_Static_assert(offsetof(struct demod_state, volume) == 1835624, "demod_state.volume");
+_Static_assert(offsetof(struct demod_state, prev_lpr_index) == 1835632, "demod_state.prev_lpr_index");
+_Static_assert(offsetof(struct demod_state, lpr) == 1835640, "demod_state.lpr");
+_Static_assert(offsetof(struct demod_state, rw) == 1835720, "demod_state.rw");
+_Static_assert(offsetof(struct demod_state, ready) == 1835776, "demod_state.ready");
+_Static_assert(offsetof(struct demod_state, ready_m) == 1835824, "demod_state.ready_m");
+_Static_assert(offsetof(struct demod_state, output_target) == 1835864, "demod_state.output_target");
+_Static_assert(sizeof(struct demod_state) == 1835872, "sizeof(struct demod_state)");
+_Static_assert(sizeof(struct lp_real) == 80, "sizeof(struct lp_real)");
+_Static_assert(offsetof(struct lp_real, swf) == 48, "lp_real.swf");
+_Static_assert(offsetof(struct lp_real, pos) == 60, "lp_real.pos");
+_Static_assert(offsetof(struct lp_real, mode) == 72, "lp_real.mode");
+
+#define FMD_PI 3.14159265f   /* PI_F  include/rtl_fm_player.h:40 */
+#define FMD_2PI 6.28318531f  /* PI2_F include/rtl_fm_player.h:39 */
+
+static __thread char g_err[256];
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+const char *fmd_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(FMD_E_HIP, "%s failed: %s (%d)", #expr, hipGetErrorString(e_), (int)e_); \
+  } while (0)
+
+int fmd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+/* ---- filter design: init_lp_f32 / init_lp_real_f32 restated ------------- */
+
+float fmd_deemph_lambda(int output_rate, double tau) {
+  return (float)exp(-1.0 / ((double)output_rate * tau));   /* src/rtl_fm_player.c:1577 */
+}
+
+static void design_fb(float *fb) {   /* src/rtl_fm_player.c:241-251 */
+  for (int i = 0; i < 16; i++) {
+    float j = (float)i - 15.5f;
+    fb[i] = (sinf(0.125f * FMD_PI * j) / (FMD_PI * j)) * (0.54f - 0.46f * cosf(FMD_PI * (float)i / 15.5f));
+  }
+}
+
+static void design_mpx(int size, int rate_in, float *fm, float *fp, float *fs, float *swf, float *cwf) {
+  /* src/rtl_fm_player.c:420-452 */
+  const float rate = (float)rate_in;
+  const float wf = FMD_2PI * 19000.0f / rate;
+  *swf = sinf(wf);
+  *cwf = cosf(wf);
+  const float fmh = 16000.0f / rate, fpl = 18000.0f / rate, fph = 20000.0f / rate;
+  const float fsl = 21000.0f / rate, fsh = 55000.0f / rate;
+  for (int i = 0; i < (size >> 1); i++) {
+    const float fi = (float)i - (float)(size - 1) / 2.0f;
+    const float fh = 0.54f - 0.46f * cosf(FMD_2PI * (float)i / (float)(size - 1));
+    float fv;
+    fv = (fi == 0) ? 2.0f * fmh : sinf(FMD_2PI * fmh * fi) / (FMD_PI * fi);
+    fm[i] = fv * fh;
+    fv = (fi == 0) ? 2.0f * (fph - fpl) : (sinf(FMD_2PI * fph * fi) - sinf(FMD_2PI * fpl * fi)) / (FMD_PI * fi);
+    fp[i] = fv * fh;
+    fv = (fi == 0) ? 2.0f * (fsh - fsl) : (sinf(FMD_2PI * fsh * fi) - sinf(FMD_2PI * fsl * fi)) / (FMD_PI * fi);
+    fs[i] = fv * fh;
+  }
+}
+
+static int check_config(const fmd_config *c) {
+  if (!c) return fail(FMD_E_ARG, "config is NULL");
+  if (c->rate_in <= 0) return fail(FMD_E_ARG, "rate_in must be positive");
+  if (c->mode < 0 || c->mode > 2) return fail(FMD_E_ARG, "lpr.mode must be 0, 1 or 2");
+  if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
+  if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
+  if (c->math != FMD_MATH_EXACT && c->math != FMD_MATH_FAST) return fail(FMD_E_ARG, "math must be exact or fast");
+  if (c->rate_out2 > 0) {
+    if (c->rate_out <= 0 || c->rate_out > 2000000) return fail(FMD_E_UNSUPPORTED, "rate_out must be 1..2000000");
+    if (c->rate_out2 > c->rate_out)
+      return fail(FMD_E_UNSUPPORTED, "rate_out2 > rate_out overflows the reference's accumulator");
+    /* stereo writes two outputs per emit over its own input; beyond 1/3 the
+     * in-place overwrite reaches more than the block's second sample */
+    if (c->mode == 2 && 3LL * c->rate_out2 > c->rate_out)
+      return fail(FMD_E_UNSUPPORTED, "stereo needs rate_out2 <= rate_out / 3");
+  } else if (c->mode == 2) {
+    return fail(FMD_E_UNSUPPORTED, "stereo without the resampler is not supported");
+  }
+  return FMD_OK;
+}
+
+int fmd_design_taps(const fmd_config *cfg, fmd_taps *out) {
+  if (!out) return fail(FMD_E_ARG, "taps is NULL");
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  memset(out, 0, sizeof(*out));
+  design_fb(out->fb);
+  design_mpx(cfg->size, cfg->rate_in, out->fm, out->fp, out->fs, &out->swf, &out->cwf);
+  return FMD_OK;
+}
+
+/* ---- batch object --------------------------------------------------------- */
+
+struct fmd_ingest;
+
+struct fmd_batch {
+  fmd_config cfg;
+  fmd_taps taps;
+  fmdk_params kp;
+  int n_streams;
+  int device;
+  int pcm_stride;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  int timed;
+  void *d_state;               /* fmd_stream_state[n_streams] */
+  /* staging for the host-buffer path, grown on demand */
+  void *d_iq, *d_pcm, *d_lens;
+  size_t cap_blocks;
+  /* ingest */
+  struct fmd_ingest **ingest;  /* [n_streams], NULL when unbound */
+  uint8_t *pump_iq;            /* pinned host staging for fmd_batch_pump */
+  size_t pump_cap;
+};
+
+static int max_result_len(const fmd_config *c) {
+  const long m = c->block_len / 16;
+  long n;
+  if (c->rate_out2 > 0) n = (m * (long)c->rate_out2) / c->rate_out + 1;
+  else n = m;
+  if (c->mode == 2) n *= 2;
+  return (int)n;
+}
+
+static void fill_params(fmd_batch *b) {
+  fmdk_params *k = &b->kp;
+  const fmd_config *c = &b->cfg;
+  memset(k, 0, sizeof(*k));
+  memcpy(k->fb, b->taps.fb, sizeof(k->fb));
+  memcpy(k->fm, b->taps.fm, sizeof(k->fm));
+  memcpy(k->fp, b->taps.fp, sizeof(k->fp));
+  memcpy(k->fs, b->taps.fs, sizeof(k->fs));
+  /* fast path of the /8 low-pass: y = sum_j ts[j] * u[j] + c with the
+   * (u - 127.5)/128 conversion and the j^n rotation signs folded in */
+  double ci = 0, cq = 0;
+  for (int j = 0; j < 32; j++) {
+    const float tap = b->taps.fb[j < 16 ? j : 31 - j];
+    const int p = j & 3;
+    float si = 1.f, sq = 1.f;
+    if (!c->offset_tuning) {
+      si = (p == 0 || p == 3) ? 1.f : -1.f;
+      sq = (p == 0 || p == 1) ? 1.f : -1.f;
+    }
+    k->ts_i[j] = si * tap / 128.0f;
+    k->ts_q[j] = sq * tap / 128.0f;
+    ci += (double)(si * tap);
+    cq += (double)(sq * tap);
+  }
+  k->c_i = (float)(-(127.5 / 128.0) * ci);
+  k->c_q = (float)(-(127.5 / 128.0) * cq);
+  k->swf = b->taps.swf;
+  k->cwf = b->taps.cwf;
+  k->lambda = c->deemph_lambda;
+  k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */
+  k->size = c->size;
+  k->half = c->size >> 1;
+  k->mode = c->mode;
+  k->slow = c->rate_out2 > 0 ? c->rate_out2 : 1;
+  k->fast = c->rate_out2 > 0 ? c->rate_out : 1;
+  k->resample = c->rate_out2 > 0;
+  k->deemph = c->deemph != 0;
+  k->offset_tuning = c->offset_tuning != 0;
+  /* restart distance for the de-emphasis recurrence: lambda^warm < 1e-12 */
+  int warm = 0;
+  if (k->deemph) {
+    const double lam = fabs((double)c->deemph_lambda);
+    if (lam <= 0.0) warm = 1;
+    else if (lam >= 1.0) warm = 1 << 30;   /* not contracting: never restart */
+    else warm = (int)ceil(log(1e-12) / log(lam));
+    if (warm < 16) warm = 16;
+  }
+  k->warm = warm;
+  k->block_len = c->block_len;
+  k->pcm_stride = b->pcm_stride;
+}
+
+int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *taps, int n_streams,
+                     int device) {
+  if (!out) return fail(FMD_E_ARG, "out is NULL");
+  *out = NULL;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (n_streams <= 0) return fail(FMD_E_ARG, "n_streams must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMD_E_NODEVICE, "no HIP device: the MI355X path has no CPU fallback");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= ndev) return fail(FMD_E_ARG, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
+  if (!b) return fail(FMD_E_NOMEM, "out of host memory");
+  b->cfg = *cfg;
+  b->n_streams = n_streams;
+  b->device = device;
+  if (taps) b->taps = *taps;
+  else if ((rc = fmd_design_taps(cfg, &b->taps))) { free(b); return rc; }
+  b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
+  fill_params(b);
+
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&b->ev0)) != hipSuccess || (e = hipEventCreate(&b->ev1)) != hipSuccess ||
+      (e = hipMalloc(&b->d_state, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
+      (e = hipMemset(b->d_state, 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess) {
+    rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e));
+    fmd_batch_destroy(b);
+    return rc;
+  }
+  b->ingest = (struct fmd_ingest **)calloc((size_t)n_streams, sizeof(*b->ingest));
+  if (!b->ingest) { fmd_batch_destroy(b); return fail(FMD_E_NOMEM, "out of host memory"); }
+  *out = b;
+  return FMD_OK;
+}
+
+void fmd_batch_destroy(fmd_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  if (b->d_state) hipFree(b->d_state);
+  if (b->d_iq) hipFree(b->d_iq);
+  if (b->d_pcm) hipFree(b->d_pcm);
+  if (b->d_lens) hipFree(b->d_lens);
+  if (b->pump_iq) hipHostFree(b->pump_iq);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->stream) hipStreamDestroy(b->stream);
+  free(b->ingest);
+  free(b);
+}
+
+int fmd_batch_pcm_stride(const fmd_batch *b) { return b ? b->pcm_stride : FMD_E_ARG; }
+int fmd_batch_n_streams(const fmd_batch *b) { return b ? b->n_streams : FMD_E_ARG; }
+const char *fmd_batch_kernel_name(const fmd_batch *b) {
+  return b ? fmdk_kernel_name(&b->kp, b->cfg.math) : "";
+}
+
+int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm, void *d_lens,
+                               void *hip_stream, const fmd_debug_taps *dbg) {
+  if (!b || !d_iq || !d_pcm || !d_lens) return fail(FMD_E_ARG, "NULL argument");
+  if (n_blocks < 0) return fail(FMD_E_ARG, "n_blocks < 0");
+  if (n_blocks == 0) return FMD_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->stream;
+  fmdk_params kp = b->kp;
+  kp.n_blocks = n_blocks;
+  HIP_TRY(hipEventRecord(b->ev0, st));
+  int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state, dbg, st);
+  if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
+  HIP_TRY(hipEventRecord(b->ev1, st));
+  b->timed = 1;
+  return FMD_OK;
+}
+
+int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm, void *d_lens,
+                         void *hip_stream) {
+  return fmd_batch_run_device_debug(b, d_iq, n_blocks, d_pcm, d_lens, hip_stream, NULL);
+}
+
+int fmd_batch_sync(fmd_batch *b) {
+  if (!b) return fail(FMD_E_ARG, "NULL batch");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return FMD_OK;
+}
+
+int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms) {
+  if (!b || !ms) return fail(FMD_E_ARG, "NULL argument");
+  if (!b->timed) return fail(FMD_E_STATE, "no kernel has been launched yet");
+  HIP_TRY(hipEventSynchronize(b->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+  return FMD_OK;
+}
+
+static int ensure_staging(fmd_batch *b, int n_blocks) {
+  if ((size_t)n_blocks <= b->cap_blocks) return FMD_OK;
+  if (b->d_iq) hipFree(b->d_iq);
+  if (b->d_pcm) hipFree(b->d_pcm);
+  if (b->d_lens) hipFree(b->d_lens);
+  b->d_iq = b->d_pcm = b->d_lens = NULL;
+  b->cap_blocks = 0;
+  const size_t slots = (size_t)b->n_streams * (size_t)n_blocks;
+  HIP_TRY(hipMalloc(&b->d_iq, slots * (size_t)b->cfg.block_len));
+  HIP_TRY(hipMalloc(&b->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t)));
+  HIP_TRY(hipMalloc(&b->d_lens, slots * sizeof(int32_t)));
+  b->cap_blocks = (size_t)n_blocks;
+  return FMD_OK;
+}
+
+int fmd_batch_run_host(fmd_batch *b, const uint8_t *iq, int n_blocks, int16_t *pcm, int32_t *lens) {
+  if (!b || !iq || !pcm || !lens) return fail(FMD_E_ARG, "NULL argument");
+  if (n_blocks <= 0) return fail(FMD_E_ARG, "n_blocks must be positive");
+  HIP_TRY(hipSetDevice(b->device));
+  int rc = ensure_staging(b, n_blocks);
+  if (rc) return rc;
+  const size_t slots = (size_t)b->n_streams * (size_t)n_blocks;
+  HIP_TRY(hipMemcpyAsync(b->d_iq, iq, slots * (size_t)b->cfg.block_len, hipMemcpyHostToDevice, b->stream));
+  rc = fmd_batch_run_device(b, b->d_iq, n_blocks, b->d_pcm, b->d_lens, NULL);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t),
+                         hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemcpyAsync(lens, b->d_lens, slots * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return FMD_OK;
+}
+
+int fmd_batch_get_state(fmd_batch *b, int stream, fmd_stream_state *out) {
+  if (!b || !out || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, (char *)b->d_state + sizeof(*out) * (size_t)stream, sizeof(*out),
+                    hipMemcpyDeviceToHost));
+  return FMD_OK;
+}
+
+int fmd_batch_set_state(fmd_batch *b, int stream, const fmd_stream_state *in) {
+  if (!b || !in || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy((char *)b->d_state + sizeof(*in) * (size_t)stream, in, sizeof(*in),
+                    hipMemcpyHostToDevice));
+  return FMD_OK;
+}
+
+int fmd_batch_reset(fmd_batch *b) {
+  if (!b) return fail(FMD_E_ARG, "NULL batch");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemset(b->d_state, 0, sizeof(fmd_stream_state) * (size_t)b->n_streams));
+  return FMD_OK;
+}
+
+/* ---- reference-shaped surface --------------------------------------------- */
+/*
+ * One single-stream batch per demod_state, found through a small registry
+ * keyed by the struct's address (the reference struct has no spare pointer
+ * field).  The batch is (re)built when the parameters that shape the kernels
+ * change.  State lives in the struct between calls, like in the reference.
+ */
+struct drop_in {
+  struct demod_state *key;
+  fmd_batch *batch;
+  fmd_config cfg;
+  int convert_mode;   /* 0: rotate_90_u8_f32, 1: u8_f32 */
+};
+
+#define DROP_IN_MAX 64
+static struct drop_in g_drop[DROP_IN_MAX];
+static pthread_mutex_t g_drop_m = PTHREAD_MUTEX_INITIALIZER;
+
+static struct drop_in *drop_find(struct demod_state *d, int create) {
+  struct drop_in *hit = NULL, *empty = NULL;
+  pthread_mutex_lock(&g_drop_m);
+  for (int i = 0; i < DROP_IN_MAX; i++) {
+    if (g_drop[i].key == d) { hit = &g_drop[i]; break; }
+    if (!g_drop[i].key && !empty) empty = &g_drop[i];
+  }
+  if (!hit && create && empty) {
+    memset(empty, 0, sizeof(*empty));
+    empty->key = d;
+    hit = empty;
+  }
+  pthread_mutex_unlock(&g_drop_m);
+  return hit;
+}
+
+static void die(const char *what) {
+  fprintf(stderr, "fmdemod_mi355x: %s: %s\n", what, fmd_last_error());
+  abort();
+}
+
+void init_u8_f32_table(void) {}  /* the conversion is arithmetic on the device (exact, no table) */
+void init_lp_f32(void) {}        /* taps are designed per batch in fmd_design_taps              */
+
+void demod_init(struct demod_state *s) {   /* src/rtl_fm_player.c:1156-1195 */
+  s->rate_in = 240000;
+  s->rate_out = 240000;
+  s->squelch_level = 0;
+  s->conseq_squelch = 10;
+  s->terminate_on_squelch = 0;
+  s->squelch_hits = 11;
+  s->downsample_passes = 0;
+  s->comp_fir_size = 0;
+  s->prev_index = 0;
+  s->post_downsample = 1;
+  s->custom_atan = 1;
+  s->deemph = 0.000050;
+  s->offset_tuning = 0;
+  s->rate_out2 = 48000;
+  s->pre_j = s->pre_r = s->now_r = s->now_j = 0;
+  s->pre_j_f32 = s->pre_r_f32 = 0;
+  s->prev_lpr_index = 0;
+  s->deemph_a = 0;
+  s->deemph_l = 0;
+  s->deemph_r = 0;
+  s->deemph_l_f32 = 0;
+  s->deemph_r_f32 = 0;
+  s->volume = 0.4f;
+  s->now_lpr = 0;
+  s->lpr.mode = 2;
+  s->lpr.size = 90;
+  s->lpr.br = s->lpr.bm = s->lpr.bs = NULL;
+  s->lpr.fm = s->lpr.fp = s->lpr.fs = NULL;
+  pthread_rwlock_init(&s->rw, NULL);
+  pthread_cond_init(&s->ready, NULL);
+  pthread_mutex_init(&s->ready_m, NULL);
+  s->output_target = NULL;
+}
+
+void init_lp_real_f32(struct demod_state *fm) {   /* src/rtl_fm_player.c:413-453 */
+  struct lp_real *l = &fm->lpr;
+  l->rsize = l->size >> 1;
+  l->pp = 0;
+  l->pos = 0;
+  l->br = (float *)calloc((size_t)l->size, 4);
+  l->bm = (float *)calloc((size_t)l->size, 4);
+  l->bs = (float *)calloc((size_t)l->size, 4);
+  l->fm = (float *)calloc((size_t)l->rsize, 4);
+  l->fp = (float *)calloc((size_t)l->rsize, 4);
+  l->fs = (float *)calloc((size_t)l->rsize, 4);
+  design_mpx(l->size, fm->rate_in, l->fm, l->fp, l->fs, &l->swf, &l->cwf);
+}
+
+void fmd_demod_release(struct demod_state *d) {
+  struct drop_in *di = drop_find(d, 0);
+  if (!di) return;
+  fmd_batch_destroy(di->batch);
+  pthread_mutex_lock(&g_drop_m);
+  memset(di, 0, sizeof(*di));
+  pthread_mutex_unlock(&g_drop_m);
+}
+
+void deinit_lp_real_f32(struct demod_state *fm) {   /* src/rtl_fm_player.c:455-470 */
+  struct lp_real *l = &fm->lpr;
+  fmd_demod_release(fm);
+  l->rsize = 0;
+  free(l->br); free(l->bm); free(l->bs); free(l->fm); free(l->fp); free(l->fs);
+  l->br = l->bm = l->bs = l->fm = l->fp = l->fs = NULL;
+}
+
+void rotate_90_u8_f32(struct demod_state *d) {   /* src/rtl_fm_player.c:206-226 */
+  struct drop_in *di = drop_find(d, 1);
+  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("rotate_90_u8_f32"); }
+  di->convert_mode = 0;
+  d->lp_len = (int)d->buf_len;
+}
+
+void u8_f32(struct demod_state *d) {             /* src/rtl_fm_player.c:228-239 */
+  struct drop_in *di = drop_find(d, 1);
+  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("u8_f32"); }
+  di->convert_mode = 1;
+  d->lp_len = (int)d->buf_len;
+}
+
+/* ring (write index pos) -> linear oldest-first */
+static void ring_to_linear(const float *ring, int size, int pos, float *lin) {
+  for (int i = 0; i < size; i++) lin[i] = ring[(pos + i) % size];
+}
+static void linear_to_ring(const float *lin, int size, int pos, float *ring) {
+  for (int i = 0; i < size; i++) ring[(pos + i) % size] = lin[i];
+}
+
+void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 */
+  struct drop_in *di = drop_find(d, 1);
+  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("full_demod"); }
+  if (!d->lpr.br || !d->lpr.fm) { fail(FMD_E_STATE, "init_lp_real_f32 was not called"); die("full_demod"); }
+  const int math = getenv("FMD_MATH_FAST") ? FMD_MATH_FAST : FMD_MATH_EXACT;
+  fmd_config c = {d->rate_in, d->rate_out, d->rate_out2, d->lpr.mode, d->lpr.size, d->deemph != 0.0,
+                  di->convert_mode, d->deemph_lambda, d->volume, (int32_t)d->buf_len, math};
+  if (!di->batch || memcmp(&c, &di->cfg, sizeof(c)) != 0) {
+    fmd_batch_destroy(di->batch);
+    di->batch = NULL;
+    fmd_taps t;
+    memset(&t, 0, sizeof(t));
+    design_fb(t.fb);
+    memcpy(t.fm, d->lpr.fm, sizeof(float) * (size_t)(d->lpr.size >> 1));   /* the caller's own tables */
+    memcpy(t.fp, d->lpr.fp, sizeof(float) * (size_t)(d->lpr.size >> 1));
+    memcpy(t.fs, d->lpr.fs, sizeof(float) * (size_t)(d->lpr.size >> 1));
+    t.swf = d->lpr.swf;
+    t.cwf = d->lpr.cwf;
+    if (fmd_batch_create(&di->batch, &c, &t, 1, -1)) die("full_demod: fmd_batch_create");
+    di->cfg = c;
+  }
+  fmd_batch *b = di->batch;
+  const int size = d->lpr.size;
+
+  /* struct -> device state */
+  fmd_stream_state st;
+  memset(&st, 0, sizeof(st));
+  memcpy(st.tb, d->lowpass_tb, sizeof(st.tb));
+  st.pre_r = d->pre_r_f32;
+  st.pre_j = d->pre_j_f32;
+  st.pp = d->lpr.pp;
+  st.deemph_l = d->deemph_l_f32;
+  st.deemph_r = d->deemph_r_f32;
+  st.acc = d->prev_lpr_index;
+  ring_to_linear(d->lpr.br, size, d->lpr.pos, st.br);
+  ring_to_linear(d->lpr.bm, size, d->lpr.pos, st.bm);
+  ring_to_linear(d->lpr.bs, size, d->lpr.pos, st.bs);
+  if (fmd_batch_set_state(b, 0, &st)) die("full_demod: set_state");
+
+  int32_t len = 0;
+  if (fmd_batch_run_host(b, d->buf, 1, d->result, &len)) die("full_demod: run");
+  d->result_len = len;
+  d->lp_len = (int)d->buf_len >> 3;                       /* :410 */
+
+  /* device state -> struct */
+  if (fmd_batch_get_state(b, 0, &st)) die("full_demod: get_state");
+  memcpy(d->lowpass_tb, st.tb, sizeof(st.tb));
+  d->pre_r_f32 = st.pre_r;
+  d->pre_j_f32 = st.pre_j;
+  d->deemph_l_f32 = st.deemph_l;
+  d->deemph_r_f32 = st.deemph_r;
+  d->prev_lpr_index = st.acc;
+  if (d->rate_out2 > 0 && d->lpr.mode != 0) {
+    const int m = (int)(d->buf_len >> 4);
+    const int pos = (d->lpr.pos + m) % size;
+    linear_to_ring(st.br, size, pos, d->lpr.br);
+    if (d->lpr.mode == 2) {
+      linear_to_ring(st.bm, size, pos, d->lpr.bm);
+      linear_to_ring(st.bs, size, pos, d->lpr.bs);
+      d->lpr.pp = st.pp;
+    }
+    d->lpr.pos = pos;
+  }
+}
+
+/* ---- ingest ---------------------------------------------------------------- */
+
+struct fmd_ingest {
+  fmd_batch *batch;
+  int stream;
+  uint8_t *ring;          /* pinned host memory */
+  uint32_t cap, rpos, wpos, size;
+  uint64_t dropped;
+  int mute;
+  pthread_mutex_t m;
+};
+
+int fmd_ingest_create(fmd_ingest **out, fmd_batch *b, int stream, uint32_t ring_bytes) {
+  if (!out || !b || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
+  if (b->ingest[stream]) return fail(FMD_E_STATE, "stream %d already has an ingest ring", stream);
+  if (ring_bytes == 0) ring_bytes = 16u * FMD_MAXIMUM_BUF_LENGTH;   /* include/rtl_fm_player.h:65 */
+  if (ring_bytes < (uint32_t)b->cfg.block_len) return fail(FMD_E_ARG, "ring smaller than one block");
+  fmd_ingest *g = (fmd_ingest *)calloc(1, sizeof(*g));
+  if (!g) return fail(FMD_E_NOMEM, "out of host memory");
+  HIP_TRY(hipSetDevice(b->device));
+  if (hipHostMalloc((void **)&g->ring, ring_bytes, hipHostMallocDefault) != hipSuccess) {
+    free(g);
+    return fail(FMD_E_NOMEM, "pinned allocation of %u bytes failed", ring_bytes);
+  }
+  g->batch = b;
+  g->stream = stream;
+  g->cap = ring_bytes;
+  pthread_mutex_init(&g->m, NULL);
+  b->ingest[stream] = g;
+  *out = g;
+  return FMD_OK;
+}
+
+void fmd_ingest_destroy(fmd_ingest *g) {
+  if (!g) return;
+  if (g->batch && g->batch->ingest) g->batch->ingest[g->stream] = NULL;
+  hipHostFree(g->ring);
+  pthread_mutex_destroy(&g->m);
+  free(g);
+}
+
+void fmd_ingest_mute(fmd_ingest *g, int n_bytes) {
+  if (g) g->mute = n_bytes;
+}
+
+/* rtlsdr_read_async_cb_t; follows rtlsdr_callback (src/rtl_fm_player.c:790-837):
+ * optional mute fill, copy with wrap, drop-oldest accounting. */
+void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx) {
+  fmd_ingest *g = (fmd_ingest *)ctx;
+  if (!g || !buf || len == 0) return;
+  if (g->mute) {
+    uint32_t n = (uint32_t)g->mute < len ? (uint32_t)g->mute : len;
+    memset(buf, 127, n);
+    g->mute = 0;
+  }
+  pthread_mutex_lock(&g->m);
+  if (len > g->cap) {            /* keep the newest cap bytes */
+    g->dropped += len - g->cap;
+    buf += len - g->cap;
+    len = g->cap;
+  }
+  uint32_t first = g->cap - g->wpos;
+  if (first > len) first = len;
+  memcpy(g->ring + g->wpos, buf, first);
+  memcpy(g->ring, buf + first, len - first);
+  g->wpos = (g->wpos + len) % g->cap;
+  g->size += len;
+  if (g->size > g->cap) {        /* overwrote the oldest data */
+    uint32_t over = g->size - g->cap;
+    g->dropped += over;
+    g->rpos = (g->rpos + over) % g->cap;
+    g->size = g->cap;
+  }
+  pthread_mutex_unlock(&g->m);
+}
+
+uint32_t fmd_ingest_buffered(const fmd_ingest *g) { return g ? g->size : 0; }
+uint64_t fmd_ingest_dropped(const fmd_ingest *g) { return g ? g->dropped : 0; }
+
+int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens) {
+  if (!b || !pcm || !lens || max_blocks <= 0) return fail(FMD_E_ARG, "bad argument");
+  const uint32_t bl = (uint32_t)b->cfg.block_len;
+  int nb = max_blocks;
+  for (int s = 0; s < b->n_streams; s++) {
+    fmd_ingest *g = b->ingest[s];
+    if (!g) return fail(FMD_E_STATE, "stream %d has no ingest ring", s);
+    pthread_mutex_lock(&g->m);
+    int have = (int)(g->size / bl);
+    pthread_mutex_unlock(&g->m);
+    if (have < nb) nb = have;
+  }
+  if (nb == 0) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t need = (size_t)b->n_streams * (size_t)nb * bl;
+  if (need > b->pump_cap) {
+    if (b->pump_iq) hipHostFree(b->pump_iq);
+    b->pump_iq = NULL;
+    b->pump_cap = 0;
+    HIP_TRY(hipHostMalloc((void **)&b->pump_iq, need, hipHostMallocDefault));
+    b->pump_cap = need;
+  }
+  for (int s = 0; s < b->n_streams; s++) {
+    fmd_ingest *g = b->ingest[s];
+    uint8_t *dst = b->pump_iq + (size_t)s * (size_t)nb * bl;
+    const uint32_t take = (uint32_t)nb * bl;
+    pthread_mutex_lock(&g->m);
+    uint32_t first = g->cap - g->rpos;
+    if (first > take) first = take;
+    memcpy(dst, g->ring + g->rpos, first);
+    memcpy(dst + first, g->ring, take - first);
+    g->rpos = (g->rpos + take) % g->cap;
+    g->size -= take;
+    pthread_mutex_unlock(&g->m);
+  }
+  int rc = fmd_batch_run_host(b, b->pump_iq, nb, pcm, lens);
+  return rc ? rc : nb;
+}

@@ -1,0 +1,52 @@
+/*
+ * fmd_internal.h - private interface between the C host layer (fmd_host.c)
+ * and the HIP kernel launcher (fmd_kernels.hip).  Not installed.
+ */
+#ifndef FMD_INTERNAL_H
+#define FMD_INTERNAL_H
+
+#include <stdint.h>
+
+#include "fmdemod_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMDK_TILE 2048        /* rate_in samples per tile                       */
+#define FMDK_HIST 256         /* history slots kept in front of each FIR tile   */
+#define FMDK_FRAME_CAP 8192   /* pending resampler outputs (floats) before a flush */
+#define FMDK_THREADS 512
+
+/* Uniform launch parameters, passed by value in the kernarg segment so that
+ * tap reads with constant indices become scalar loads. */
+typedef struct fmdk_params {
+  float fb[16];           /* /8 IQ low-pass, half (reference lp_filter_f32)      */
+  float ts_i[32];         /* fast path: signed taps / 128 applied to the I sum   */
+  float ts_q[32];         /* fast path: signed taps / 128 applied to the Q sum   */
+  float c_i, c_q;         /* fast path: constant terms of the folded offset      */
+  float fm[128], fp[128], fs[128];
+  float swf, cwf, lambda, coef;
+  int32_t size, half, mode;
+  int32_t slow, fast;     /* rate_out2, rate_out                                 */
+  int32_t resample;       /* rate_out2 > 0                                       */
+  int32_t deemph, offset_tuning;
+  int32_t warm;           /* de-emphasis warm-up frames for restarted segments   */
+  int32_t block_len;      /* bytes per block                                     */
+  int32_t n_blocks;
+  int32_t pcm_stride;     /* int16 per (stream, block)                           */
+} fmdk_params;
+
+/* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a
+ * hipError_t (> 0).  All pointers are device pointers. */
+int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq, void *d_pcm,
+                void *d_lens, void *d_state, const fmd_debug_taps *dbg, void *hip_stream);
+/* Mangled-free kernel name as rocprofv3 prints it (prefix match). */
+const char *fmdk_kernel_name(const fmdk_params *p, int math);
+/* Static LDS bytes of the fused kernel (for DESIGN.md / diagnostics). */
+int fmdk_lds_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,648 @@
+/*
+ * fmd_kernels.hip - fused IQ -> PCM kernel for gfx950 (MI355X).
+ *
+ * One workgroup owns one stream and walks its blocks in time order, so every
+ * piece of carried state (FIR histories, pilot sample, resampler accumulator,
+ * de-emphasis) is handed from tile to tile through LDS exactly as the
+ * reference hands it from call to call.  HBM traffic is the algorithmic
+ * minimum: the u8 IQ is read once (coalesced 16 B per lane), the int16 PCM is
+ * written once; every intermediate (decimated IQ, discriminator output, the
+ * three MPX filter outputs, resampled frames) lives in LDS.
+ *
+ * Stages per tile of FMDK_TILE rate_in samples (reference src/rtl_fm_player.c):
+ *   A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
+ *   B  polynomial-atan2 FM discriminator             :606-685
+ *   Q  block-start overwrite quirk (stereo)          :534-598
+ *   C  three 90-tap MPX FIRs + 38 kHz carrier        :533-568, :472-481
+ *   D  rational resampler, second FIR at emit times  :570-598 (stereo), :500-532 (mono)
+ *   F  de-emphasis, f32 -> s16, PCM store            :687-735
+ *
+ * Two arithmetic contracts (template parameter EX):
+ *   exact: the reference's operation order with unfused multiply/add (this
+ *          file is compiled with -ffp-contract=off) -> bit-identical PCM;
+ *   fast:  same summation order with explicit fused multiply-adds and the
+ *          u8 offset folded into the decimator taps -> PCM within +-1 LSB.
+ * No MFMA: the path is int8/fp32 streaming work.
+ */
+#include <hip/hip_runtime.h>
+
+#include "fmd_internal.h"
+
+namespace {
+
+constexpr int TM = FMDK_TILE;
+constexpr int HV = FMDK_HIST;
+constexpr int CAPF = FMDK_FRAME_CAP;
+constexpr int NT = FMDK_THREADS;
+constexpr int DEEMPH_GROUP = 16;   /* frames per de-emphasis lane */
+
+constexpr float K_PI = 3.14159265f;    /* include/rtl_fm_player.h:40 */
+constexpr float K_PI_2 = 1.5707963f;   /* :41 */
+constexpr float K_PI_4 = 0.78539816f;  /* :42 */
+
+struct __attribute__((aligned(16))) Smem {
+  uint4 iq[3 + TM + 1];      /* 48 halo bytes, then 16 bytes per rate_in sample */
+  float2 y[TM + 2];          /* y[0] = last y of the previous tile, y[1+m]      */
+  float v[HV + TM];          /* discriminator, HV history slots in front        */
+  float bm[HV + TM];         /* L+R low-pass (stereo)                           */
+  float bs[HV + TM];         /* L-R band-pass, then x carrier (stereo)          */
+  float vp[4 + TM];          /* pilot band-pass; vp[3] = previous tile's last   */
+  float fr[CAPF];            /* resampler outputs waiting for the flush         */
+  float de[4];               /* de-emphasis state: [0..1] current, [2..3] next  */
+};
+
+/* ---- arithmetic helpers ------------------------------------------------ */
+
+template <bool EX>
+__device__ __forceinline__ float mac(float acc, float a, float b) {
+  if constexpr (EX) {
+    float p = a * b;       /* -ffp-contract=off keeps this unfused */
+    return acc + p;
+  } else {
+    return __builtin_fmaf(a, b, acc);
+  }
+}
+
+__device__ __forceinline__ float ubyte(uint32_t w, int i) {
+  return (float)((w >> (8 * i)) & 0xffu);   /* v_cvt_f32_ubyteN */
+}
+
+/* (u - 127.5) / 128: exact in fp32, one fused op (reference table [0]) */
+__device__ __forceinline__ float t0(float u) { return __builtin_fmaf(u, 0.0078125f, -0.99609375f); }
+
+/* src/rtl_fm_player.c:606-667 through the magnitude ratio (see oracle/fm_oracle.c) */
+template <bool EX>
+__device__ __forceinline__ float poly_atan2(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const bool xmaj = ax >= ay;
+  const float num = xmaj ? ay : ax, den = xmaj ? ax : ay;
+  const float a = num / den;                                /* IEEE divide */
+  float r0;
+  if constexpr (EX) {
+    r0 = a * (K_PI_4 - (a - 1.f) * (0.2447f + 0.0663f * a));
+  } else {
+    const float q = __builtin_fmaf(0.0663f, a, 0.2447f);
+    r0 = a * __builtin_fmaf(-(a - 1.f), q, K_PI_4);
+  }
+  float r;
+  if (x < 0.f) {
+    if (y < 0.f) r = xmaj ? r0 - K_PI : -r0 - K_PI_2;
+    else         r = xmaj ? -r0 + K_PI : K_PI_2 + r0;
+  } else {
+    if (y < 0.f) r = xmaj ? -r0 : r0 - K_PI_2;
+    else         r = xmaj ? r0 : K_PI_2 - r0;
+  }
+  if (y == 0.f) r = (x < 0.f) ? K_PI : 0.f;
+  if (x == 0.f) r = (y < 0.f) ? -K_PI_2 : ((y > 0.f) ? K_PI_2 : 0.f);
+  return r;
+}
+
+/* src/rtl_fm_player.c:472-481 */
+__device__ __forceinline__ float carrier38(float x, float y) {
+  const float z = y / x;
+  const float c = (z + z) / (1.f + (z * z));
+  return (x == 0.f) ? 0.f : c;
+}
+
+/* src/rtl_fm_player.c:711-735 */
+__device__ __forceinline__ int16_t to_s16(float x, float coef) {
+  const float t = x * coef;
+  int r = (int)__builtin_rintf(t);
+  if (t > 32767.0f) r = 32767;
+  if (t < -32768.0f) r = -32768;
+  return (int16_t)r;
+}
+
+/* ---- stage A: decimating IQ low-pass ----------------------------------- */
+
+/* Rotation by j^p of window sample with phase p (src/rtl_fm_player.c:206-226):
+ * which byte feeds the I / Q sum and with which sign. */
+template <bool ROT> __device__ __forceinline__ constexpr int sel_i(int p) { return ROT ? (p & 1) : 0; }
+template <bool ROT> __device__ __forceinline__ constexpr int sel_q(int p) { return ROT ? ((p & 1) ^ 1) : 1; }
+template <bool ROT> __device__ __forceinline__ constexpr float sgn_i(int p) {
+  return !ROT ? 1.f : ((p == 0 || p == 3) ? 1.f : -1.f);
+}
+template <bool ROT> __device__ __forceinline__ constexpr float sgn_q(int p) {
+  return !ROT ? 1.f : ((p == 0 || p == 1) ? 1.f : -1.f);
+}
+
+/* Two consecutive outputs per lane: 80 raw bytes (5 x 16 B) from the LDS tile. */
+template <bool EX, bool ROT>
+__device__ __forceinline__ void decimate_tile(Smem &s, const fmdk_params &P, int tm) {
+  for (int item = threadIdx.x; 2 * item < tm; item += NT) {
+    uint32_t d[20];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const uint4 q = s.iq[2 * item + i];
+      d[4 * i] = q.x; d[4 * i + 1] = q.y; d[4 * i + 2] = q.z; d[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      float ai, aq;
+      if constexpr (EX) {
+        /* sum_k (c[k] + c[31-k]) * fb[k], left to right (src/rtl_fm_player.c:371-403) */
+        ai = 0.f; aq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int ja = 8 * r + k, jb = 8 * r + 31 - k;     /* sample index in the 40-sample span */
+          const int pa = k & 3, pb = (31 - k) & 3;
+          const float ia = sgn_i<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_i<ROT>(pa)));
+          const float ib = sgn_i<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_i<ROT>(pb)));
+          const float qa = sgn_q<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_q<ROT>(pa)));
+          const float qb = sgn_q<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_q<ROT>(pb)));
+          const float pi = (ia + ib) * P.fb[k];
+          const float pq = (qa + qb) * P.fb[k];
+          ai = (k == 0) ? pi : ai + pi;
+          aq = (k == 0) ? pq : aq + pq;
+        }
+      } else {
+        /* offset and 1/128 folded into signed taps: sum_j ts[j] * u[j] + c */
+        ai = P.c_i; aq = P.c_q;
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+          const int js = 8 * r + j, p = j & 3;
+          ai = __builtin_fmaf(P.ts_i[j], ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
+          aq = __builtin_fmaf(P.ts_q[j], ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
+        }
+      }
+      const int m = 2 * item + r;
+      if (m < tm) s.y[1 + m] = make_float2(ai, aq);
+    }
+  }
+}
+
+/* First three outputs of the first block of a launch: their window reaches
+ * into the carried float history lowpass_tb (src/rtl_fm_player.c:261-363). */
+template <bool EX, bool ROT>
+__device__ __forceinline__ void decimate_head(Smem &s, const fmdk_params &P, const float *tb, int tm) {
+  const int lane = threadIdx.x;
+  if (lane < 6 && (lane >> 1) < tm) {
+    const int m = lane >> 1, comp = lane & 1;
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq) + 48;
+    float acc = 0.f;
+    for (int k = 0; k < 16; k++) {
+      float pr[2];
+      for (int e = 0; e < 2; e++) {
+        const int j = e ? 31 - k : k;
+        const int g = 8 * m - 24 + j;          /* sample index within the block */
+        float c;
+        if (g < 0) {
+          c = tb[2 * (24 + g) + comp];
+        } else {
+          const int p = j & 3;
+          const int sel = comp ? sel_q<ROT>(p) : sel_i<ROT>(p);
+          const float sg = comp ? sgn_q<ROT>(p) : sgn_i<ROT>(p);
+          c = sg * t0((float)raw[2 * g + sel]);
+        }
+        pr[e] = c;
+      }
+      const float prod = (pr[0] + pr[1]) * P.fb[k];
+      acc = (k == 0) ? prod : acc + prod;
+    }
+    float2 *yy = &s.y[1 + m];
+    if (comp) yy->y = acc; else yy->x = acc;
+  }
+}
+
+/* ---- stage B: discriminator --------------------------------------------- */
+
+template <bool EX>
+__device__ __forceinline__ void discriminate_tile(Smem &s, int tm) {
+  for (int m = threadIdx.x; m < tm; m += NT) {
+    const float2 p = s.y[m], c = s.y[m + 1];
+    float cr, dt;
+    if constexpr (EX) {
+      cr = p.x * c.y - p.y * c.x;          /* pre_r * Q - pre_j * I */
+      dt = c.x * p.x + c.y * p.y;          /* I * pre_r + Q * pre_j */
+    } else {
+      cr = __builtin_fmaf(p.x, c.y, -(p.y * c.x));
+      dt = __builtin_fmaf(c.x, p.x, c.y * p.y);
+    }
+    s.v[HV + m] = poly_atan2<EX>(cr, dt);
+  }
+}
+
+/* ---- stage C: MPX filters at rate_in (stereo) --------------------------- */
+
+/* Four consecutive outputs per lane from a 96-float register window. */
+template <bool EX, int HALF>
+__device__ __forceinline__ void mpx_tile(Smem &s, const fmdk_params &P, int tm) {
+  constexpr int S = 2 * HALF;
+  if constexpr (HALF == 45) {
+    constexpr int R = 4;
+    for (int item = threadIdx.x; R * item < tm; item += NT) {
+      const int m0 = R * item;
+      float w[96];                       /* w[i] = v[m0 - 92 + i] */
+      const float4 *src = reinterpret_cast<const float4 *>(&s.v[HV + m0 - 92]);
+#pragma unroll
+      for (int i = 0; i < 24; i++) {
+        const float4 q = src[i];
+        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+      }
+      float am[R], ap[R], as[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < HALF; k++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float p = w[r + k + 3] + w[r + 92 - k];   /* oldest + k, newest - k */
+          am[r] = mac<EX>(am[r], p, P.fm[k]);
+          ap[r] = mac<EX>(ap[r], p, P.fp[k]);
+          as[r] = mac<EX>(as[r], p, P.fs[k]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (m0 + r < tm) {
+          s.bm[HV + m0 + r] = am[r];
+          s.vp[4 + m0 + r] = ap[r];
+          s.bs[HV + m0 + r] = as[r];     /* multiplied by the carrier in carrier_tile */
+        }
+      }
+    }
+  } else {
+    const int half = P.half, size = P.size;
+    (void)S;
+    for (int m = threadIdx.x; m < tm; m += NT) {
+      const float *w = &s.v[HV + m - (size - 1)];
+      float am = 0.f, ap = 0.f, as = 0.f;
+      for (int k = 0; k < half; k++) {
+        const float p = w[k] + w[size - 1 - k];
+        am = mac<EX>(am, p, P.fm[k]);
+        ap = mac<EX>(ap, p, P.fp[k]);
+        as = mac<EX>(as, p, P.fs[k]);
+      }
+      s.bm[HV + m] = am;
+      s.vp[4 + m] = ap;
+      s.bs[HV + m] = as;
+    }
+  }
+}
+
+/* bs[m] = vs[m] * sin2atan2(vp[m] * swf, vp[m] * cwf - vp[m-1])  (:565-566) */
+template <bool EX>
+__device__ __forceinline__ void carrier_tile(Smem &s, const fmdk_params &P, int tm) {
+  for (int m = threadIdx.x; m < tm; m += NT) {
+    const float vp = s.vp[4 + m], vq = s.vp[3 + m];
+    const float x = vp * P.swf;
+    float y;
+    if constexpr (EX) y = vp * P.cwf - vq;
+    else y = __builtin_fmaf(vp, P.cwf, -vq);
+    s.bs[HV + m] *= carrier38(x, y);
+  }
+}
+
+/* One symmetric FIR over the newest `size` entries ending at w_end (inclusive). */
+template <bool EX, int HALF>
+__device__ __forceinline__ float fir_at(const float *newest, const fmdk_params &P) {
+  float acc = 0.f;
+  if constexpr (HALF > 0) {
+    constexpr int S = 2 * HALF;
+    const float *w = newest - (S - 1);
+#pragma unroll
+    for (int k = 0; k < HALF; k++) acc = mac<EX>(acc, w[k] + w[S - 1 - k], P.fm[k]);
+  } else {
+    const int size = P.size, half = P.half;
+    const float *w = newest - (size - 1);
+    for (int k = 0; k < half; k++) acc = mac<EX>(acc, w[k] + w[size - 1 - k], P.fm[k]);
+  }
+  return acc;
+}
+
+/* Block-start quirk (src/rtl_fm_player.c:534-598):
+ * when the resampler emits on sample 0 of a block, the right-channel output is
+ * stored over discriminator sample 1 before that sample is read. */
+template <bool EX, int HALF>
+__device__ __forceinline__ void q1_patch(Smem &s, const fmdk_params &P) {
+  const int lane = threadIdx.x;
+  float f = 0.f;
+  if (lane < 3) {
+    const int size = P.size, half = P.half;
+    const float *w = &s.v[HV - (size - 1)];
+    const float *tap = lane == 0 ? P.fm : (lane == 1 ? P.fp : P.fs);
+    for (int k = 0; k < half; k++) f = mac<EX>(f, w[k] + w[size - 1 - k], tap[k]);
+  }
+  const float vp = __shfl(f, 1), vs = __shfl(f, 2);
+  if (lane == 0) {
+    const float vq = s.vp[3];
+    const float x = vp * P.swf;
+    float y;
+    if constexpr (EX) y = vp * P.cwf - vq;
+    else y = __builtin_fmaf(vp, P.cwf, -vq);
+    s.bm[HV] = f;
+    s.bs[HV] = vs * carrier38(x, y);
+  }
+  __syncthreads();
+  float o = 0.f;
+  if (lane < 2) o = fir_at<EX, HALF>(lane == 0 ? &s.bm[HV] : &s.bs[HV], P);
+  const float om = __shfl(o, 0), os = __shfl(o, 1);
+  if (lane == 0) s.v[HV + 1] = om - os;
+  __syncthreads();
+}
+
+/* ---- stage D: resampler outputs ------------------------------------------ */
+
+/* local index of the q-th emit of this tile; acc_t = accumulator at tile start */
+__device__ __forceinline__ int emit_index(const fmdk_params &P, uint32_t acc_t, int q) {
+  if (!P.resample) return q;
+  const uint32_t need = (uint32_t)(q + 1) * (uint32_t)P.fast - acc_t;   /* > 0 */
+  return (int)((need + (uint32_t)P.slow - 1u) / (uint32_t)P.slow) - 1;
+}
+
+template <bool EX, int MODE, int HALF>
+__device__ __forceinline__ void resample_tile(Smem &s, const fmdk_params &P, uint32_t acc_t, int nq,
+                                              int pend) {
+  if constexpr (MODE == 2) {
+    for (int task = threadIdx.x; task < 2 * nq; task += NT) {
+      const int q = task >> 1, which = task & 1;
+      const int i = emit_index(P, acc_t, q);
+      const float *newest = (which ? s.bs : s.bm) + HV + i;
+      s.fr[pend + task] = fir_at<EX, HALF>(newest, P);   /* om / os; L,R formed at the flush */
+    }
+  } else if constexpr (MODE == 1) {
+    for (int q = threadIdx.x; q < nq; q += NT) {
+      const int i = emit_index(P, acc_t, q);
+      s.fr[pend + q] = fir_at<EX, HALF>(&s.v[HV + i], P);
+    }
+  } else {
+    for (int q = threadIdx.x; q < nq; q += NT) s.fr[pend + q] = s.v[HV + emit_index(P, acc_t, q)];
+  }
+}
+
+/* ---- stage F: de-emphasis + s16 + store ----------------------------------- */
+
+template <bool EX, int MODE>
+__device__ __forceinline__ float frame_value(const Smem &s, int f, int c) {
+  if constexpr (MODE == 2) {
+    const float om = s.fr[2 * f], os = s.fr[2 * f + 1];
+    return c ? om - os : om + os;            /* :595-596 */
+  } else {
+    return s.fr[f];
+  }
+}
+
+/* De-emphasis is a first-order recurrence (:687-709).  Each lane produces
+ * DEEMPH_GROUP consecutive frames of one channel; a lane whose segment does not
+ * start at the first pending frame restarts the recurrence P.warm frames early
+ * from zero (lambda^warm < 1e-12, below fp32 resolution), the others continue
+ * from the carried state, so the result equals the sequential evaluation. */
+template <bool EX, int MODE>
+__device__ __forceinline__ void flush_frames(Smem &s, const fmdk_params &P, int pend, int16_t *pcm_out,
+                                             float *mpx_dbg) {
+  constexpr int CH = (MODE == 2) ? 2 : 1;
+  const int frames = pend / CH;
+  if (mpx_dbg) {
+    for (int i = threadIdx.x; i < pend; i += NT) mpx_dbg[i] = frame_value<EX, MODE>(s, i / CH, i % CH);
+  }
+  if (P.deemph) {
+    const int groups = (frames + DEEMPH_GROUP - 1) / DEEMPH_GROUP;
+    const float lam = P.lambda;
+    for (int task = threadIdx.x; task < groups * CH; task += NT) {
+      const int g = task / CH, c = task % CH;
+      const int f_out = g * DEEMPH_GROUP;
+      int f = f_out - P.warm;
+      float y = 0.f;
+      if (f <= 0) { f = 0; y = s.de[c]; }
+      const int f_end = min(f_out + DEEMPH_GROUP, frames);
+      for (; f < f_end; f++) {
+        const float x = frame_value<EX, MODE>(s, f, c);
+        const float t = y - x;
+        if constexpr (EX) y = x + lam * t;
+        else y = __builtin_fmaf(lam, t, x);
+        if (f >= f_out) pcm_out[f * CH + c] = to_s16(y, P.coef);
+      }
+      if (f_end == frames) s.de[2 + c] = y;
+    }
+    __syncthreads();
+    if (threadIdx.x < CH && frames > 0) s.de[threadIdx.x] = s.de[2 + threadIdx.x];
+  } else {
+    for (int i = threadIdx.x; i < pend; i += NT)
+      pcm_out[i] = to_s16(frame_value<EX, MODE>(s, i / CH, i % CH), P.coef);
+  }
+  __syncthreads();
+}
+
+/* ---- carried state in HBM ------------------------------------------------- */
+
+struct DevState {   /* == fmd_stream_state */
+  float tb[48];
+  float pre_r, pre_j, pp, de_l, de_r;
+  int32_t acc;
+  int32_t reserved[2];
+  float br[256], bm[256], bs[256];
+};
+static_assert(sizeof(DevState) == sizeof(fmd_stream_state), "state layout");
+
+/* ---- the fused kernel ----------------------------------------------------- */
+
+template <bool EX, int MODE, int HALF>
+__global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
+                                                      int16_t *__restrict__ pcm_all,
+                                                      int32_t *__restrict__ lens_all,
+                                                      DevState *__restrict__ state_all, float *dbg_y,
+                                                      float *dbg_v, float *dbg_mpx) {
+  __shared__ Smem s;
+  constexpr int CH = (MODE == 2) ? 2 : 1;
+  const int tid = threadIdx.x;
+  const int stream = blockIdx.x;
+  const int M = P.block_len >> 4;                 /* rate_in samples per block */
+  const int size = P.size;
+  DevState *st = state_all + stream;
+  const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
+
+  /* carried state -> LDS */
+  for (int i = tid; i < size; i += NT) {
+    s.v[HV - size + i] = st->br[i];
+    if constexpr (MODE == 2) {
+      s.bm[HV - size + i] = st->bm[i];
+      s.bs[HV - size + i] = st->bs[i];
+    }
+  }
+  if (tid == 0) {
+    s.y[0] = make_float2(st->pre_r, st->pre_j);
+    s.vp[3] = st->pp;
+    s.de[0] = st->de_l;
+    s.de[1] = st->de_r;
+  }
+  uint32_t acc = (uint32_t)st->acc;               /* uniform */
+  __syncthreads();
+
+  for (int b = 0; b < P.n_blocks; b++) {
+    const uint8_t *iq_blk = iq_stream + (size_t)b * P.block_len;
+    const size_t slot = (size_t)stream * P.n_blocks + b;
+    int16_t *pcm_blk = pcm_all + slot * P.pcm_stride;
+    float *mpx_blk = dbg_mpx ? dbg_mpx + slot * M : nullptr;
+    int pend = 0, pcm_off = 0;
+    const bool q1 = (MODE == 2) && P.resample && (acc + (uint32_t)P.slow >= (uint32_t)P.fast);
+
+    for (int t0s = 0; t0s < M; t0s += TM) {
+      const int tm = min(TM, M - t0s);
+      const bool head = (b == 0 && t0s == 0);
+
+      /* -- load the raw IQ tile (+48 B halo) into LDS, 16 B per lane -- */
+      {
+        const uint4 *src = reinterpret_cast<const uint4 *>(iq_blk + (size_t)t0s * 16) - 3;
+        const int n16 = tm + 3;
+        for (int i = tid; i < n16; i += NT) {
+          uint4 q;
+          if (head && i < 3) q = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+          else q = src[i];
+          s.iq[i] = q;
+        }
+        if (tid == 0) s.iq[n16] = make_uint4(0, 0, 0, 0);   /* pad read by an odd last item */
+      }
+      __syncthreads();
+
+      /* -- A: /8 low-pass -- */
+      if (P.offset_tuning) decimate_tile<EX, false>(s, P, tm);
+      else decimate_tile<EX, true>(s, P, tm);
+      if (head) {
+        __syncthreads();
+        if (P.offset_tuning) decimate_head<EX, false>(s, P, st->tb, tm);
+        else decimate_head<EX, true>(s, P, st->tb, tm);
+      }
+      __syncthreads();
+      if (dbg_y) {
+        float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s;
+        for (int m = tid; m < tm; m += NT) o[m] = s.y[1 + m];
+      }
+
+      /* -- B: discriminator -- */
+      discriminate_tile<EX>(s, tm);
+      __syncthreads();
+      if (dbg_v) {
+        float *o = dbg_v + slot * M + t0s;
+        for (int m = tid; m < tm; m += NT) o[m] = s.v[HV + m];
+      }
+
+      /* -- Q + C: stereo MPX filters -- */
+      if constexpr (MODE == 2) {
+        if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>(s, P);
+        mpx_tile<EX, HALF>(s, P, tm);
+        __syncthreads();
+        carrier_tile<EX>(s, P, tm);
+        __syncthreads();
+      }
+
+      /* -- D: resampler outputs of this tile -- */
+      int nq;
+      if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * (uint32_t)P.slow) /
+                                 (uint32_t)P.fast);
+      else nq = tm;
+      if (pend + nq * CH > CAPF) {
+        flush_frames<EX, MODE>(s, P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+        pcm_off += pend;
+        pend = 0;
+      }
+      resample_tile<EX, MODE, HALF>(s, P, acc, nq, pend);
+      pend += nq * CH;
+      if (P.resample)
+        acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * (uint32_t)P.slow) %
+                         (uint32_t)P.fast);
+      __syncthreads();
+
+      /* -- roll the histories to the front of their buffers -- */
+      {
+        float hv = 0.f, hm = 0.f, hs = 0.f;
+        if (tid < HV) {
+          hv = s.v[tm + tid];
+          if constexpr (MODE == 2) { hm = s.bm[tm + tid]; hs = s.bs[tm + tid]; }
+        }
+        float2 ylast = s.y[tm];
+        float vplast = s.vp[3 + tm];
+        __syncthreads();
+        if (tid < HV) {
+          s.v[tid] = hv;
+          if constexpr (MODE == 2) { s.bm[tid] = hm; s.bs[tid] = hs; }
+        }
+        if (tid == 0) {
+          s.y[0] = ylast;
+          if constexpr (MODE == 2) s.vp[3] = vplast;
+        }
+        /* the next tile's first barrier orders these writes before any read */
+      }
+    }
+
+    /* -- F: end of block -> PCM -- */
+    __syncthreads();
+    flush_frames<EX, MODE>(s, P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+    if (tid == 0) lens_all[slot] = pcm_off + pend;
+  }
+
+  /* carried state -> HBM */
+  __syncthreads();
+  if (P.n_blocks > 0) {
+    /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
+    if (tid < 48) {
+      const int tm_last = (M % TM) ? (M % TM) : TM;
+      const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq) + 16 * tm_last;   /* 48 bytes */
+      const int j = tid >> 1, comp = tid & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
+      int sel; float sg;
+      if (P.offset_tuning) { sel = comp; sg = 1.f; }
+      else {
+        sel = comp ? sel_q<true>(p) : sel_i<true>(p);
+        sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
+      }
+      st->tb[tid] = sg * t0((float)raw[2 * j + sel]);
+    }
+    for (int i = tid; i < size; i += NT) {
+      st->br[i] = s.v[HV - size + i];
+      if constexpr (MODE == 2) {
+        st->bm[i] = s.bm[HV - size + i];
+        st->bs[i] = s.bs[HV - size + i];
+      }
+    }
+    if (tid == 0) {
+      st->pre_r = s.y[0].x;
+      st->pre_j = s.y[0].y;
+      if constexpr (MODE == 2) st->pp = s.vp[3];
+      st->de_l = s.de[0];
+      st->de_r = s.de[1];
+      st->acc = (int32_t)acc;
+    }
+  }
+}
+
+template <bool EX, int MODE, int HALF>
+int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens, void *state,
+               const fmd_debug_taps *dbg, hipStream_t stream) {
+  hipLaunchKernelGGL((fmd_fused_kernel<EX, MODE, HALF>), dim3(n_streams), dim3(NT), 0, stream, *p,
+                     static_cast<const uint8_t *>(iq), static_cast<int16_t *>(pcm),
+                     static_cast<int32_t *>(lens), static_cast<DevState *>(state),
+                     dbg ? static_cast<float *>(dbg->y) : nullptr,
+                     dbg ? static_cast<float *>(dbg->v) : nullptr,
+                     dbg ? static_cast<float *>(dbg->mpx) : nullptr);
+  return (int)hipGetLastError();
+}
+
+template <bool EX>
+int launch_math(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens, void *state,
+                const fmd_debug_taps *dbg, hipStream_t stream) {
+  if (p->mode == 2) {
+    if (p->half == 45) return launch_one<EX, 2, 45>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+    return launch_one<EX, 2, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+  }
+  if (p->mode == 1) {
+    if (p->half == 64) return launch_one<EX, 1, 64>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+    return launch_one<EX, 1, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+  }
+  return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+}
+
+}  // namespace
+
+extern "C" int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq, void *d_pcm,
+                           void *d_lens, void *d_state, const fmd_debug_taps *dbg, void *hip_stream) {
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (math == FMD_MATH_EXACT) return launch_math<true>(p, n_streams, d_iq, d_pcm, d_lens, d_state, dbg, st);
+  return launch_math<false>(p, n_streams, d_iq, d_pcm, d_lens, d_state, dbg, st);
+}
+
+extern "C" const char *fmdk_kernel_name(const fmdk_params *p, int math) {
+  (void)p;
+  (void)math;
+  return "fmd_fused_kernel";
+}
+
+extern "C" int fmdk_lds_bytes(void) { return (int)sizeof(Smem); }

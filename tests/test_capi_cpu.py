@@ -1,0 +1,80 @@
+"""CPU-side checks of the C ABI: the library loads, exports every declared
+symbol, validates configurations and designs the reference's filter tables.
+No kernel is launched here (no GPU in this container)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import rtl_fm_player_amd as R
+from rtl_fm_player_amd import capi
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    R.build_library()
+
+
+def test_every_declared_symbol_is_exported():
+    import os
+    hdr = open(os.path.join(os.path.dirname(capi.__file__), "..", "include", "fmdemod_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(\w+)\s*\([^;{}]*\)\s*;", hdr)) - {"fmd_read_async_cb_t", "void"}
+    declared = {d for d in declared if not d.startswith("_")}
+    L = R.lib()
+    missing = [d for d in sorted(declared) if not hasattr(L, d)]
+    assert not missing, missing
+    assert set(capi.exported_symbols()) <= declared | {"fmd_demod_release"}
+    assert len(declared) >= 30
+
+
+def test_struct_layout_matches_reference():
+    D = capi.DemodState
+    assert C.sizeof(D) == 1835872
+    assert (D.buf.offset, D.buf_len.offset, D.lowpassed.offset) == (16, 262160, 262164)
+    assert (D.lowpass_tb.offset, D.result.offset, D.result_len.offset) == (1310744, 1311176, 1835464)
+    assert (D.rate_in.offset, D.pre_r_f32.offset, D.deemph.offset) == (1835508, 1835536, 1835592)
+    assert (D.prev_lpr_index.offset, D.lpr.offset, D.output_target.offset) == (1835632, 1835640, 1835864)
+    assert C.sizeof(capi.LpReal) == 80 and capi.LpReal.pos.offset == 60
+
+
+def test_design_taps_equals_oracle():
+    from oracle import OracleStream
+    for kw in (dict(rate_in=300000, mode=2), dict(rate_in=300000, mode=1), dict(rate_in=25000, rate_out2=12500, mode=1)):
+        cfg = R.wbfm_config(**kw)
+        t = R.design_taps(cfg)
+        o = OracleStream(**kw).taps()
+        h = cfg.size // 2
+        assert np.array_equal(np.array(t.fb[:], np.float32), o["fb"])
+        assert np.array_equal(np.array(t.fm[:h], np.float32), o["fm"])
+        assert np.array_equal(np.array(t.fp[:h], np.float32), o["fp"])
+        assert np.array_equal(np.array(t.fs[:h], np.float32), o["fs"])
+        assert (t.swf, t.cwf) == (o["swf"], o["cwf"])
+        assert cfg.deemph_lambda == OracleStream(**kw).cfg.deemph_lambda
+
+
+@pytest.mark.parametrize("bad", [
+    dict(block_len=100), dict(block_len=32), dict(size=91), dict(size=300), dict(mode=3),
+    dict(rate_out2=200000),          # stereo beyond rate_out / 3
+    dict(rate_out2=0, mode=2),
+])
+def test_bad_configs_are_rejected(bad):
+    cfg = R.wbfm_config(**bad)
+    t = capi.FmdTaps()
+    assert R.lib().fmd_design_taps(C.byref(cfg), C.byref(t)) < 0
+    assert R.lib().fmd_last_error()
+
+
+def test_create_without_device_fails_loudly():
+    if R.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(R.FmdError, match="no HIP device"):
+        R.BatchDemod(R.wbfm_config(), 1)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(R.FmdError, match="no CPU fallback"):
+        capi.lib()
