@@ -44,7 +44,7 @@ def cpu_baseline(cfg_kw, seconds):
     """The oracle (a bit-exact CPU port of the reference path) on this host's cores:
     one independent stream per thread, bounded sample of the same workload."""
     from oracle import OracleStream, lcg_bytes
-    n_thr = os.cpu_count() or 1
+    n_thr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nb = 8
     iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
     streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
@@ -103,7 +103,8 @@ def main():
     iq = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=g)
     pcm = torch.zeros((S, B, batch.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(device=dev)          # kernels and timing events share this stream
+    torch.cuda.synchronize(dev)
 
     def step():
         batch.run_device(iq, B, pcm, lens, hip_stream=stream.cuda_stream)

@@ -190,9 +190,12 @@ typedef struct fmd_stream_state {
 /* Optional stage taps for debugging / parity tests: device pointers or NULL.
  * Shapes per stream and block, M = block_len / 16:
  *   y [2*M] f32, v [M] f32 (before the Q1 overwrite), mpx [M] f32 (resampler
- *   output before de-emphasis, result_len entries used). */
+ *   output before de-emphasis, result_len entries used).  prof: see below. */
 typedef struct fmd_debug_taps {
   void *y, *v, *mpx;
+  void *prof;   /* i64 [n_streams][16]: shader-clock cycles per stage, summed over the launch
+                   (0 load, 1 decimate, 2 discriminate, 3 q1, 4 mpx, 5 carrier, 6 resample,
+                    7 roll, 8 flush, 9 state in/out, 15 total) */
 } fmd_debug_taps;
 
 typedef struct fmd_batch fmd_batch;

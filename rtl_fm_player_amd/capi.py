@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -53,7 +54,7 @@ class FmdStreamState(C.Structure):
 
 
 class FmdDebugTaps(C.Structure):
-    _fields_ = [("y", C.c_void_p), ("v", C.c_void_p), ("mpx", C.c_void_p)]
+    _fields_ = [("y", C.c_void_p), ("v", C.c_void_p), ("mpx", C.c_void_p), ("prof", C.c_void_p)]
 
 
 class LpReal(C.Structure):          # struct lp_real
@@ -113,6 +114,13 @@ def lib():
         return _lib
     if not os.path.exists(_LIB):
         raise FmdError("%s is missing: run __graft_entry__.build() (there is no CPU fallback)" % _LIB)
+    # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process break the
+    # second one, so when torch is installed let it load first and share its copy.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(_LIB)
     vp = C.c_void_p
     L.fmd_design_taps.argtypes = [C.POINTER(FmdConfig), C.POINTER(FmdTaps)]
@@ -221,7 +229,7 @@ class BatchDemod:
                                             _ptr(hip_stream))
         else:
             dbg = FmdDebugTaps(*[(_ptr(debug.get(k)).value if debug.get(k) is not None else None)
-                                 for k in ("y", "v", "mpx")])
+                                 for k in ("y", "v", "mpx", "prof")])
             rc = lib().fmd_batch_run_device_debug(self._h, _ptr(d_iq), n_blocks, _ptr(d_pcm), _ptr(d_lens),
                                                   _ptr(hip_stream), C.byref(dbg))
         _check(rc, "fmd_batch_run_device")

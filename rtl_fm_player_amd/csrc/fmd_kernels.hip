@@ -5,9 +5,10 @@
  * piece of carried state (FIR histories, pilot sample, resampler accumulator,
  * de-emphasis) is handed from tile to tile through LDS exactly as the
  * reference hands it from call to call.  HBM traffic is the algorithmic
- * minimum: the u8 IQ is read once (coalesced 16 B per lane), the int16 PCM is
- * written once; every intermediate (decimated IQ, discriminator output, the
- * three MPX filter outputs, resampled frames) lives in LDS.
+ * minimum: the u8 IQ is read once (16 B per lane, straight into LDS with
+ * global_load_lds, one tile ahead of the arithmetic), the int16 PCM is written
+ * once; every intermediate (decimated IQ, discriminator output, the three MPX
+ * filter outputs, resampled frames) lives in LDS.
  *
  * Stages per tile of FMDK_TILE rate_in samples (reference src/rtl_fm_player.c):
  *   A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
@@ -23,6 +24,13 @@
  *   fast:  same summation order with explicit fused multiply-adds and the
  *          u8 offset folded into the decimator taps -> PCM within +-1 LSB.
  * No MFMA: the path is int8/fp32 streaming work.
+ *
+ * Code shape: the kernel body is a small uniform control loop; each stage is a
+ * separate (noinline) device function working on the one file-scope LDS
+ * object, so every stage gets its own register allocation instead of one
+ * 7000-instruction body whose hoisted invariants spill.  Filter taps live in
+ * LDS and are read with wave-uniform addresses (broadcast): ~200 taps do not
+ * fit the scalar register file.
  */
 #include <hip/hip_runtime.h>
 
@@ -34,22 +42,44 @@ constexpr int TM = FMDK_TILE;
 constexpr int HV = FMDK_HIST;
 constexpr int CAPF = FMDK_FRAME_CAP;
 constexpr int NT = FMDK_THREADS;
+constexpr int NW = NT / 64;
 constexpr int DEEMPH_GROUP = 16;   /* frames per de-emphasis lane */
 
 constexpr float K_PI = 3.14159265f;    /* include/rtl_fm_player.h:40 */
 constexpr float K_PI_2 = 1.5707963f;   /* :41 */
 constexpr float K_PI_4 = 0.78539816f;  /* :42 */
 
+struct Ctl {               /* uniform scalars the stage functions need */
+  float swf, cwf, lambda, coef, c_i, c_q, inv_slow;
+  int size, half, slow, fast, resample, deemph, warm, offset_tuning;
+};
+
 struct __attribute__((aligned(16))) Smem {
-  uint4 iq[3 + TM + 1];      /* 48 halo bytes, then 16 bytes per rate_in sample */
+  uint4 iq[2][TM + 4];       /* double buffer: 48 halo bytes, then 16 bytes per rate_in sample */
   float2 y[TM + 2];          /* y[0] = last y of the previous tile, y[1+m]      */
   float v[HV + TM];          /* discriminator, HV history slots in front        */
   float bm[HV + TM];         /* L+R low-pass (stereo)                           */
   float bs[HV + TM];         /* L-R band-pass, then x carrier (stereo)          */
   float vp[4 + TM];          /* pilot band-pass; vp[3] = previous tile's last   */
   float fr[CAPF];            /* resampler outputs waiting for the flush         */
+  float4 tap_mpx[128];       /* {fm[k], fp[k], fs[k], 0}: one broadcast read per k */
+  float2 tap_dec[32];        /* fast /8 low-pass: {ts_i[j], ts_q[j]}            */
+  float fb[16];              /* exact /8 low-pass half taps                     */
   float de[4];               /* de-emphasis state: [0..1] current, [2..3] next  */
+  Ctl ctl;
 };
+
+__shared__ Smem g_s;
+
+/* LDS-only workgroup barrier: does not drain outstanding global_load_lds /
+ * global stores (a __syncthreads() would add s_waitcnt vmcnt(0)). */
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+/* Barrier that also waits for this wave's global_load_lds writes to land. */
+__device__ __forceinline__ void full_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 /* ---- arithmetic helpers ------------------------------------------------ */
 
@@ -113,6 +143,23 @@ __device__ __forceinline__ int16_t to_s16(float x, float coef) {
   return (int16_t)r;
 }
 
+/* ---- tile load: global -> LDS, asynchronous ------------------------------ */
+
+/* Copies 16-byte chunks [first, n16) of src into g_s.iq[buf].  Each wave
+ * instruction moves 64 lanes x 16 B to a contiguous 1 KiB of LDS
+ * (global_load_lds: wave-uniform LDS base + lane * 16). */
+__device__ __noinline__ void load_tile_async(const uint4 *src, int buf, int first, int n16) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int base = first + 64 * wave; base < n16; base += 64 * NW) {
+    const int i = base + lane;
+    if (i < n16) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(src + i),
+          (__attribute__((address_space(3))) void *)(&g_s.iq[buf][base]), 16, 0, 0);
+    }
+  }
+}
+
 /* ---- stage A: decimating IQ low-pass ----------------------------------- */
 
 /* Rotation by j^p of window sample with phase p (src/rtl_fm_player.c:206-226):
@@ -128,12 +175,13 @@ template <bool ROT> __device__ __forceinline__ constexpr float sgn_q(int p) {
 
 /* Two consecutive outputs per lane: 80 raw bytes (5 x 16 B) from the LDS tile. */
 template <bool EX, bool ROT>
-__device__ __forceinline__ void decimate_tile(Smem &s, const fmdk_params &P, int tm) {
+__device__ __noinline__ void decimate_tile(int buf, int tm) {
+  Smem &s = g_s;
   for (int item = threadIdx.x; 2 * item < tm; item += NT) {
     uint32_t d[20];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      const uint4 q = s.iq[2 * item + i];
+      const uint4 q = s.iq[buf][2 * item + i];
       d[4 * i] = q.x; d[4 * i + 1] = q.y; d[4 * i + 2] = q.z; d[4 * i + 3] = q.w;
     }
 #pragma unroll
@@ -150,19 +198,21 @@ __device__ __forceinline__ void decimate_tile(Smem &s, const fmdk_params &P, int
           const float ib = sgn_i<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_i<ROT>(pb)));
           const float qa = sgn_q<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_q<ROT>(pa)));
           const float qb = sgn_q<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_q<ROT>(pb)));
-          const float pi = (ia + ib) * P.fb[k];
-          const float pq = (qa + qb) * P.fb[k];
+          const float fbk = s.fb[k];
+          const float pi = (ia + ib) * fbk;
+          const float pq = (qa + qb) * fbk;
           ai = (k == 0) ? pi : ai + pi;
           aq = (k == 0) ? pq : aq + pq;
         }
       } else {
         /* offset and 1/128 folded into signed taps: sum_j ts[j] * u[j] + c */
-        ai = P.c_i; aq = P.c_q;
+        ai = s.ctl.c_i; aq = s.ctl.c_q;
 #pragma unroll
         for (int j = 0; j < 32; j++) {
           const int js = 8 * r + j, p = j & 3;
-          ai = __builtin_fmaf(P.ts_i[j], ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
-          aq = __builtin_fmaf(P.ts_q[j], ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
+          const float2 tj = s.tap_dec[j];
+          ai = __builtin_fmaf(tj.x, ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
+          aq = __builtin_fmaf(tj.y, ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
         }
       }
       const int m = 2 * item + r;
@@ -173,12 +223,13 @@ __device__ __forceinline__ void decimate_tile(Smem &s, const fmdk_params &P, int
 
 /* First three outputs of the first block of a launch: their window reaches
  * into the carried float history lowpass_tb (src/rtl_fm_player.c:261-363). */
-template <bool EX, bool ROT>
-__device__ __forceinline__ void decimate_head(Smem &s, const fmdk_params &P, const float *tb, int tm) {
+template <bool ROT>
+__device__ __noinline__ void decimate_head(int buf, const float *tb, int tm) {
+  Smem &s = g_s;
   const int lane = threadIdx.x;
   if (lane < 6 && (lane >> 1) < tm) {
     const int m = lane >> 1, comp = lane & 1;
-    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq) + 48;
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[buf]) + 48;
     float acc = 0.f;
     for (int k = 0; k < 16; k++) {
       float pr[2];
@@ -196,7 +247,7 @@ __device__ __forceinline__ void decimate_head(Smem &s, const fmdk_params &P, con
         }
         pr[e] = c;
       }
-      const float prod = (pr[0] + pr[1]) * P.fb[k];
+      const float prod = (pr[0] + pr[1]) * s.fb[k];
       acc = (k == 0) ? prod : acc + prod;
     }
     float2 *yy = &s.y[1 + m];
@@ -207,7 +258,8 @@ __device__ __forceinline__ void decimate_head(Smem &s, const fmdk_params &P, con
 /* ---- stage B: discriminator --------------------------------------------- */
 
 template <bool EX>
-__device__ __forceinline__ void discriminate_tile(Smem &s, int tm) {
+__device__ __noinline__ void discriminate_tile(int tm) {
+  Smem &s = g_s;
   for (int m = threadIdx.x; m < tm; m += NT) {
     const float2 p = s.y[m], c = s.y[m + 1];
     float cr, dt;
@@ -226,8 +278,8 @@ __device__ __forceinline__ void discriminate_tile(Smem &s, int tm) {
 
 /* Four consecutive outputs per lane from a 96-float register window. */
 template <bool EX, int HALF>
-__device__ __forceinline__ void mpx_tile(Smem &s, const fmdk_params &P, int tm) {
-  constexpr int S = 2 * HALF;
+__device__ __noinline__ void mpx_tile(int tm) {
+  Smem &s = g_s;
   if constexpr (HALF == 45) {
     constexpr int R = 4;
     for (int item = threadIdx.x; R * item < tm; item += NT) {
@@ -244,12 +296,15 @@ __device__ __forceinline__ void mpx_tile(Smem &s, const fmdk_params &P, int tm) 
       for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
 #pragma unroll
       for (int k = 0; k < HALF; k++) {
+        /* keep the tap reads near their use: hoisting all 45 of them costs 180 VGPRs */
+        if (k % 5 == 0) asm volatile("" ::: "memory");
+        const float4 tk = s.tap_mpx[k];
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const float p = w[r + k + 3] + w[r + 92 - k];   /* oldest + k, newest - k */
-          am[r] = mac<EX>(am[r], p, P.fm[k]);
-          ap[r] = mac<EX>(ap[r], p, P.fp[k]);
-          as[r] = mac<EX>(as[r], p, P.fs[k]);
+          am[r] = mac<EX>(am[r], p, tk.x);
+          ap[r] = mac<EX>(ap[r], p, tk.y);
+          as[r] = mac<EX>(as[r], p, tk.z);
         }
       }
 #pragma unroll
@@ -262,16 +317,16 @@ __device__ __forceinline__ void mpx_tile(Smem &s, const fmdk_params &P, int tm) 
       }
     }
   } else {
-    const int half = P.half, size = P.size;
-    (void)S;
+    const int half = s.ctl.half, size = s.ctl.size;
     for (int m = threadIdx.x; m < tm; m += NT) {
       const float *w = &s.v[HV + m - (size - 1)];
       float am = 0.f, ap = 0.f, as = 0.f;
       for (int k = 0; k < half; k++) {
         const float p = w[k] + w[size - 1 - k];
-        am = mac<EX>(am, p, P.fm[k]);
-        ap = mac<EX>(ap, p, P.fp[k]);
-        as = mac<EX>(as, p, P.fs[k]);
+        const float4 tk = s.tap_mpx[k];
+        am = mac<EX>(am, p, tk.x);
+        ap = mac<EX>(ap, p, tk.y);
+        as = mac<EX>(as, p, tk.z);
       }
       s.bm[HV + m] = am;
       s.vp[4 + m] = ap;
@@ -280,147 +335,204 @@ __device__ __forceinline__ void mpx_tile(Smem &s, const fmdk_params &P, int tm) 
   }
 }
 
-/* bs[m] = vs[m] * sin2atan2(vp[m] * swf, vp[m] * cwf - vp[m-1])  (:565-566) */
 template <bool EX>
-__device__ __forceinline__ void carrier_tile(Smem &s, const fmdk_params &P, int tm) {
-  for (int m = threadIdx.x; m < tm; m += NT) {
-    const float vp = s.vp[4 + m], vq = s.vp[3 + m];
-    const float x = vp * P.swf;
-    float y;
-    if constexpr (EX) y = vp * P.cwf - vq;
-    else y = __builtin_fmaf(vp, P.cwf, -vq);
-    s.bs[HV + m] *= carrier38(x, y);
-  }
+__device__ __forceinline__ float carrier_of(float vp, float vq, float swf, float cwf) {
+  const float x = vp * swf;
+  float y;
+  if constexpr (EX) y = vp * cwf - vq;
+  else y = __builtin_fmaf(vp, cwf, -vq);
+  return carrier38(x, y);
 }
 
-/* One symmetric FIR over the newest `size` entries ending at w_end (inclusive). */
+/* bs[m] = vs[m] * sin2atan2(vp[m] * swf, vp[m] * cwf - vp[m-1])  (:565-566) */
+template <bool EX>
+__device__ __noinline__ void carrier_tile(int tm) {
+  Smem &s = g_s;
+  const float swf = s.ctl.swf, cwf = s.ctl.cwf;
+  for (int m = threadIdx.x; m < tm; m += NT)
+    s.bs[HV + m] *= carrier_of<EX>(s.vp[4 + m], s.vp[3 + m], swf, cwf);
+}
+
+/* Symmetric FIR with the fm taps over the `size` entries ending at newest. */
 template <bool EX, int HALF>
-__device__ __forceinline__ float fir_at(const float *newest, const fmdk_params &P) {
+__device__ __forceinline__ float fir_at(const float *newest) {
+  const Smem &s = g_s;
   float acc = 0.f;
   if constexpr (HALF > 0) {
     constexpr int S = 2 * HALF;
     const float *w = newest - (S - 1);
 #pragma unroll
-    for (int k = 0; k < HALF; k++) acc = mac<EX>(acc, w[k] + w[S - 1 - k], P.fm[k]);
+    for (int k = 0; k < HALF; k++) acc = mac<EX>(acc, w[k] + w[S - 1 - k], s.tap_mpx[k].x);
   } else {
-    const int size = P.size, half = P.half;
+    const int size = s.ctl.size, half = s.ctl.half;
     const float *w = newest - (size - 1);
-    for (int k = 0; k < half; k++) acc = mac<EX>(acc, w[k] + w[size - 1 - k], P.fm[k]);
+    for (int k = 0; k < half; k++) acc = mac<EX>(acc, w[k] + w[size - 1 - k], s.tap_mpx[k].x);
   }
   return acc;
+}
+
+/* Two such FIRs (L+R and L-R histories) at the same instant, sharing the taps. */
+template <bool EX, int HALF>
+__device__ __forceinline__ void fir2_at(const float *nm, const float *ns, float &om, float &os) {
+  const Smem &s = g_s;
+  om = 0.f; os = 0.f;
+  if constexpr (HALF > 0) {
+    constexpr int S = 2 * HALF;
+    const float *wm = nm - (S - 1), *ws = ns - (S - 1);
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+      const float t = s.tap_mpx[k].x;
+      om = mac<EX>(om, wm[k] + wm[S - 1 - k], t);
+      os = mac<EX>(os, ws[k] + ws[S - 1 - k], t);
+    }
+  } else {
+    const int size = s.ctl.size, half = s.ctl.half;
+    const float *wm = nm - (size - 1), *ws = ns - (size - 1);
+    for (int k = 0; k < half; k++) {
+      const float t = s.tap_mpx[k].x;
+      om = mac<EX>(om, wm[k] + wm[size - 1 - k], t);
+      os = mac<EX>(os, ws[k] + ws[size - 1 - k], t);
+    }
+  }
 }
 
 /* Block-start quirk (src/rtl_fm_player.c:534-598):
  * when the resampler emits on sample 0 of a block, the right-channel output is
  * stored over discriminator sample 1 before that sample is read. */
 template <bool EX, int HALF>
-__device__ __forceinline__ void q1_patch(Smem &s, const fmdk_params &P) {
+__device__ __noinline__ void q1_patch() {
+  Smem &s = g_s;
   const int lane = threadIdx.x;
   float f = 0.f;
   if (lane < 3) {
-    const int size = P.size, half = P.half;
+    const int size = s.ctl.size, half = s.ctl.half;
     const float *w = &s.v[HV - (size - 1)];
-    const float *tap = lane == 0 ? P.fm : (lane == 1 ? P.fp : P.fs);
-    for (int k = 0; k < half; k++) f = mac<EX>(f, w[k] + w[size - 1 - k], tap[k]);
+    const float *tap = reinterpret_cast<const float *>(s.tap_mpx) + lane;
+    for (int k = 0; k < half; k++) f = mac<EX>(f, w[k] + w[size - 1 - k], tap[4 * k]);
   }
   const float vp = __shfl(f, 1), vs = __shfl(f, 2);
   if (lane == 0) {
-    const float vq = s.vp[3];
-    const float x = vp * P.swf;
-    float y;
-    if constexpr (EX) y = vp * P.cwf - vq;
-    else y = __builtin_fmaf(vp, P.cwf, -vq);
     s.bm[HV] = f;
-    s.bs[HV] = vs * carrier38(x, y);
+    s.bs[HV] = vs * carrier_of<EX>(vp, s.vp[3], s.ctl.swf, s.ctl.cwf);
   }
-  __syncthreads();
-  float o = 0.f;
-  if (lane < 2) o = fir_at<EX, HALF>(lane == 0 ? &s.bm[HV] : &s.bs[HV], P);
-  const float om = __shfl(o, 0), os = __shfl(o, 1);
-  if (lane == 0) s.v[HV + 1] = om - os;
-  __syncthreads();
+  lds_barrier();
+  if (lane == 0) {
+    float om, os;
+    fir2_at<EX, HALF>(&s.bm[HV], &s.bs[HV], om, os);
+    s.v[HV + 1] = om - os;
+  }
+  lds_barrier();
 }
 
 /* ---- stage D: resampler outputs ------------------------------------------ */
 
-/* local index of the q-th emit of this tile; acc_t = accumulator at tile start */
-__device__ __forceinline__ int emit_index(const fmdk_params &P, uint32_t acc_t, int q) {
-  if (!P.resample) return q;
-  const uint32_t need = (uint32_t)(q + 1) * (uint32_t)P.fast - acc_t;   /* > 0 */
-  return (int)((need + (uint32_t)P.slow - 1u) / (uint32_t)P.slow) - 1;
+/* local index of the q-th emit of this tile; acc_t = accumulator at tile start.
+ * i = ceil(((q+1) * fast - acc_t) / slow) - 1, by a float estimate corrected
+ * with exact integer checks. */
+__device__ __forceinline__ int emit_index(uint32_t acc_t, int q, uint32_t slow, uint32_t fast,
+                                          float inv_slow) {
+  const uint32_t need = (uint32_t)(q + 1) * fast - acc_t;   /* > 0 */
+  uint32_t e = (uint32_t)((float)need * inv_slow);
+  if (e * slow < need) e++;
+  else if (e > 0 && (e - 1) * slow >= need) e--;
+  if (e * slow < need) e++;
+  return (int)e - 1;
 }
 
 template <bool EX, int MODE, int HALF>
-__device__ __forceinline__ void resample_tile(Smem &s, const fmdk_params &P, uint32_t acc_t, int nq,
-                                              int pend) {
-  if constexpr (MODE == 2) {
-    for (int task = threadIdx.x; task < 2 * nq; task += NT) {
-      const int q = task >> 1, which = task & 1;
-      const int i = emit_index(P, acc_t, q);
-      const float *newest = (which ? s.bs : s.bm) + HV + i;
-      s.fr[pend + task] = fir_at<EX, HALF>(newest, P);   /* om / os; L,R formed at the flush */
+__device__ __noinline__ void resample_tile(uint32_t acc_t, int nq, int pend) {
+  Smem &s = g_s;
+  const uint32_t slow = (uint32_t)s.ctl.slow, fast = (uint32_t)s.ctl.fast;
+  const float inv_slow = s.ctl.inv_slow;
+  const bool rs = s.ctl.resample != 0;
+  for (int q = threadIdx.x; q < nq; q += NT) {
+    const int i = rs ? emit_index(acc_t, q, slow, fast, inv_slow) : q;
+    if constexpr (MODE == 2) {
+      float om, os;
+      fir2_at<EX, HALF>(&s.bm[HV + i], &s.bs[HV + i], om, os);
+      s.fr[pend + 2 * q] = om + os;          /* :595 */
+      s.fr[pend + 2 * q + 1] = om - os;      /* :596 */
+    } else if constexpr (MODE == 1) {
+      s.fr[pend + q] = fir_at<EX, HALF>(&s.v[HV + i]);
+    } else {
+      s.fr[pend + q] = s.v[HV + i];
     }
-  } else if constexpr (MODE == 1) {
-    for (int q = threadIdx.x; q < nq; q += NT) {
-      const int i = emit_index(P, acc_t, q);
-      s.fr[pend + q] = fir_at<EX, HALF>(&s.v[HV + i], P);
-    }
-  } else {
-    for (int q = threadIdx.x; q < nq; q += NT) s.fr[pend + q] = s.v[HV + emit_index(P, acc_t, q)];
   }
 }
 
 /* ---- stage F: de-emphasis + s16 + store ----------------------------------- */
 
-template <bool EX, int MODE>
-__device__ __forceinline__ float frame_value(const Smem &s, int f, int c) {
-  if constexpr (MODE == 2) {
-    const float om = s.fr[2 * f], os = s.fr[2 * f + 1];
-    return c ? om - os : om + os;            /* :595-596 */
-  } else {
-    return s.fr[f];
-  }
-}
-
 /* De-emphasis is a first-order recurrence (:687-709).  Each lane produces
  * DEEMPH_GROUP consecutive frames of one channel; a lane whose segment does not
- * start at the first pending frame restarts the recurrence P.warm frames early
+ * start at the first pending frame restarts the recurrence ctl.warm frames early
  * from zero (lambda^warm < 1e-12, below fp32 resolution), the others continue
  * from the carried state, so the result equals the sequential evaluation. */
-template <bool EX, int MODE>
-__device__ __forceinline__ void flush_frames(Smem &s, const fmdk_params &P, int pend, int16_t *pcm_out,
-                                             float *mpx_dbg) {
-  constexpr int CH = (MODE == 2) ? 2 : 1;
+template <bool EX, int CH>
+__device__ __noinline__ void flush_frames(int pend, int16_t *pcm_out, float *mpx_dbg) {
+  Smem &s = g_s;
   const int frames = pend / CH;
+  const float coef = s.ctl.coef;
   if (mpx_dbg) {
-    for (int i = threadIdx.x; i < pend; i += NT) mpx_dbg[i] = frame_value<EX, MODE>(s, i / CH, i % CH);
+    for (int i = threadIdx.x; i < pend; i += NT) mpx_dbg[i] = s.fr[i];
   }
-  if (P.deemph) {
+  if (s.ctl.deemph) {
     const int groups = (frames + DEEMPH_GROUP - 1) / DEEMPH_GROUP;
-    const float lam = P.lambda;
+    const float lam = s.ctl.lambda;
+    const int warm = s.ctl.warm;
     for (int task = threadIdx.x; task < groups * CH; task += NT) {
       const int g = task / CH, c = task % CH;
       const int f_out = g * DEEMPH_GROUP;
-      int f = f_out - P.warm;
+      int f = f_out - warm;
       float y = 0.f;
       if (f <= 0) { f = 0; y = s.de[c]; }
       const int f_end = min(f_out + DEEMPH_GROUP, frames);
-      for (; f < f_end; f++) {
-        const float x = frame_value<EX, MODE>(s, f, c);
+#pragma unroll 4
+      for (; f < f_out; f++) {             /* warm-up, nothing stored */
+        const float x = s.fr[f * CH + c];
         const float t = y - x;
         if constexpr (EX) y = x + lam * t;
         else y = __builtin_fmaf(lam, t, x);
-        if (f >= f_out) pcm_out[f * CH + c] = to_s16(y, P.coef);
+      }
+      for (; f < f_end; f++) {
+        const float x = s.fr[f * CH + c];
+        const float t = y - x;
+        if constexpr (EX) y = x + lam * t;
+        else y = __builtin_fmaf(lam, t, x);
+        pcm_out[f * CH + c] = to_s16(y, coef);
       }
       if (f_end == frames) s.de[2 + c] = y;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < CH && frames > 0) s.de[threadIdx.x] = s.de[2 + threadIdx.x];
   } else {
-    for (int i = threadIdx.x; i < pend; i += NT)
-      pcm_out[i] = to_s16(frame_value<EX, MODE>(s, i / CH, i % CH), P.coef);
+    for (int i = threadIdx.x; i < pend; i += NT) pcm_out[i] = to_s16(s.fr[i], coef);
   }
-  __syncthreads();
+  lds_barrier();
+}
+
+/* ---- history roll ---------------------------------------------------------- */
+
+template <int MODE>
+__device__ __noinline__ void roll_history(int tm) {
+  Smem &s = g_s;
+  const int tid = threadIdx.x;
+  float hv = 0.f, hm = 0.f, hs = 0.f;
+  if (tid < HV) {
+    hv = s.v[tm + tid];
+    if constexpr (MODE == 2) { hm = s.bm[tm + tid]; hs = s.bs[tm + tid]; }
+  }
+  const float2 ylast = s.y[tm];
+  const float vplast = s.vp[3 + tm];
+  lds_barrier();
+  if (tid < HV) {
+    s.v[tid] = hv;
+    if constexpr (MODE == 2) { s.bm[tid] = hm; s.bs[tid] = hs; }
+  }
+  if (tid == 0) {
+    s.y[0] = ylast;
+    if constexpr (MODE == 2) s.vp[3] = vplast;
+  }
+  /* the next barrier orders these writes before any read */
 }
 
 /* ---- carried state in HBM ------------------------------------------------- */
@@ -434,24 +546,13 @@ struct DevState {   /* == fmd_stream_state */
 };
 static_assert(sizeof(DevState) == sizeof(fmd_stream_state), "state layout");
 
-/* ---- the fused kernel ----------------------------------------------------- */
-
-template <bool EX, int MODE, int HALF>
-__global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
-                                                      int16_t *__restrict__ pcm_all,
-                                                      int32_t *__restrict__ lens_all,
-                                                      DevState *__restrict__ state_all, float *dbg_y,
-                                                      float *dbg_v, float *dbg_mpx) {
-  __shared__ Smem s;
-  constexpr int CH = (MODE == 2) ? 2 : 1;
-  const int tid = threadIdx.x;
-  const int stream = blockIdx.x;
-  const int M = P.block_len >> 4;                 /* rate_in samples per block */
-  const int size = P.size;
-  DevState *st = state_all + stream;
-  const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
-
-  /* carried state -> LDS */
+template <int MODE>
+__device__ __forceinline__ void state_in(const fmdk_params &P, const DevState *st) {
+  Smem &s = g_s;
+  const int tid = threadIdx.x, size = P.size;
+  for (int i = tid; i < 128; i += NT) s.tap_mpx[i] = make_float4(P.fm[i], P.fp[i], P.fs[i], 0.f);
+  if (tid < 32) s.tap_dec[tid] = make_float2(P.ts_i[tid], P.ts_q[tid]);
+  if (tid < 16) s.fb[tid] = P.fb[tid];
   for (int i = tid; i < size; i += NT) {
     s.v[HV - size + i] = st->br[i];
     if constexpr (MODE == 2) {
@@ -464,144 +565,188 @@ __global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, cons
     s.vp[3] = st->pp;
     s.de[0] = st->de_l;
     s.de[1] = st->de_r;
+    Ctl c;
+    c.swf = P.swf; c.cwf = P.cwf; c.lambda = P.lambda; c.coef = P.coef;
+    c.c_i = P.c_i; c.c_q = P.c_q; c.inv_slow = 1.0f / (float)P.slow;
+    c.size = P.size; c.half = P.half; c.slow = P.slow; c.fast = P.fast;
+    c.resample = P.resample; c.deemph = P.deemph; c.warm = P.warm; c.offset_tuning = P.offset_tuning;
+    s.ctl = c;
   }
-  uint32_t acc = (uint32_t)st->acc;               /* uniform */
-  __syncthreads();
+}
 
-  for (int b = 0; b < P.n_blocks; b++) {
-    const uint8_t *iq_blk = iq_stream + (size_t)b * P.block_len;
+template <int MODE>
+__device__ __noinline__ void state_out(DevState *st, int last_buf, int tm_last, uint32_t acc) {
+  Smem &s = g_s;
+  const int tid = threadIdx.x, size = s.ctl.size;
+  /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
+  if (tid < 48) {
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[last_buf]) + 16 * tm_last;   /* 48 bytes */
+    const int j = tid >> 1, comp = tid & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
+    int sel; float sg;
+    if (s.ctl.offset_tuning) { sel = comp; sg = 1.f; }
+    else {
+      sel = comp ? sel_q<true>(p) : sel_i<true>(p);
+      sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
+    }
+    st->tb[tid] = sg * t0((float)raw[2 * j + sel]);
+  }
+  for (int i = tid; i < size; i += NT) {
+    st->br[i] = s.v[HV - size + i];
+    if constexpr (MODE == 2) {
+      st->bm[i] = s.bm[HV - size + i];
+      st->bs[i] = s.bs[HV - size + i];
+    }
+  }
+  if (tid == 0) {
+    st->pre_r = s.y[0].x;
+    st->pre_j = s.y[0].y;
+    if constexpr (MODE == 2) st->pp = s.vp[3];
+    st->de_l = s.de[0];
+    st->de_r = s.de[1];
+    st->acc = (int32_t)acc;
+  }
+}
+
+/* ---- the fused kernel ----------------------------------------------------- */
+
+template <bool EX, int MODE, int HALF>
+__global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
+                                                      int16_t *__restrict__ pcm_all,
+                                                      int32_t *__restrict__ lens_all,
+                                                      DevState *__restrict__ state_all, float *dbg_y,
+                                                      float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
+  Smem &s = g_s;
+  /* optional per-stage cycle accounting (fmd_debug_taps.prof) */
+  long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long pf_last = 0, pf_start = 0;
+  if (dbg_prof) pf_start = pf_last = clock64();
+#define FMD_STAMP(i)                                   \
+  if (dbg_prof) {                                      \
+    const long long now_ = clock64();                  \
+    pf[i] += now_ - pf_last;                           \
+    pf_last = now_;                                    \
+  }
+  constexpr int CH = (MODE == 2) ? 2 : 1;
+  const int tid = threadIdx.x;
+  const int stream = blockIdx.x;
+  const int M = P.block_len >> 4;                 /* rate_in samples per block */
+  const int tiles_per_block = (M + TM - 1) / TM;
+  const int n_tiles = tiles_per_block * P.n_blocks;
+  DevState *st = state_all + stream;
+  const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
+  const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
+
+  state_in<MODE>(P, st);
+  uint32_t acc = (uint32_t)st->acc;               /* uniform */
+
+  /* first tile: chunks 3.. (the 48 halo bytes come from the float history) */
+  if (n_tiles > 0) {
+    load_tile_async(reinterpret_cast<const uint4 *>(iq_stream) - 3, 0, 3, min(TM, M) + 3);
+    if (tid < 3) s.iq[0][tid] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  }
+  FMD_STAMP(9)
+
+  int buf = 0, tm_last = 0;
+  int pend = 0, pcm_off = 0;
+  bool q1 = false;
+  for (int tile = 0; tile < n_tiles; tile++) {
+    const int b = tile / tiles_per_block, t0s = (tile - b * tiles_per_block) * TM;
+    const int tm = min(TM, M - t0s);
+    const bool head = (tile == 0);
     const size_t slot = (size_t)stream * P.n_blocks + b;
     int16_t *pcm_blk = pcm_all + slot * P.pcm_stride;
     float *mpx_blk = dbg_mpx ? dbg_mpx + slot * M : nullptr;
-    int pend = 0, pcm_off = 0;
-    const bool q1 = (MODE == 2) && P.resample && (acc + (uint32_t)P.slow >= (uint32_t)P.fast);
-
-    for (int t0s = 0; t0s < M; t0s += TM) {
-      const int tm = min(TM, M - t0s);
-      const bool head = (b == 0 && t0s == 0);
-
-      /* -- load the raw IQ tile (+48 B halo) into LDS, 16 B per lane -- */
-      {
-        const uint4 *src = reinterpret_cast<const uint4 *>(iq_blk + (size_t)t0s * 16) - 3;
-        const int n16 = tm + 3;
-        for (int i = tid; i < n16; i += NT) {
-          uint4 q;
-          if (head && i < 3) q = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-          else q = src[i];
-          s.iq[i] = q;
-        }
-        if (tid == 0) s.iq[n16] = make_uint4(0, 0, 0, 0);   /* pad read by an odd last item */
-      }
-      __syncthreads();
-
-      /* -- A: /8 low-pass -- */
-      if (P.offset_tuning) decimate_tile<EX, false>(s, P, tm);
-      else decimate_tile<EX, true>(s, P, tm);
-      if (head) {
-        __syncthreads();
-        if (P.offset_tuning) decimate_head<EX, false>(s, P, st->tb, tm);
-        else decimate_head<EX, true>(s, P, st->tb, tm);
-      }
-      __syncthreads();
-      if (dbg_y) {
-        float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s;
-        for (int m = tid; m < tm; m += NT) o[m] = s.y[1 + m];
-      }
-
-      /* -- B: discriminator -- */
-      discriminate_tile<EX>(s, tm);
-      __syncthreads();
-      if (dbg_v) {
-        float *o = dbg_v + slot * M + t0s;
-        for (int m = tid; m < tm; m += NT) o[m] = s.v[HV + m];
-      }
-
-      /* -- Q + C: stereo MPX filters -- */
-      if constexpr (MODE == 2) {
-        if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>(s, P);
-        mpx_tile<EX, HALF>(s, P, tm);
-        __syncthreads();
-        carrier_tile<EX>(s, P, tm);
-        __syncthreads();
-      }
-
-      /* -- D: resampler outputs of this tile -- */
-      int nq;
-      if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * (uint32_t)P.slow) /
-                                 (uint32_t)P.fast);
-      else nq = tm;
-      if (pend + nq * CH > CAPF) {
-        flush_frames<EX, MODE>(s, P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-        pcm_off += pend;
-        pend = 0;
-      }
-      resample_tile<EX, MODE, HALF>(s, P, acc, nq, pend);
-      pend += nq * CH;
-      if (P.resample)
-        acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * (uint32_t)P.slow) %
-                         (uint32_t)P.fast);
-      __syncthreads();
-
-      /* -- roll the histories to the front of their buffers -- */
-      {
-        float hv = 0.f, hm = 0.f, hs = 0.f;
-        if (tid < HV) {
-          hv = s.v[tm + tid];
-          if constexpr (MODE == 2) { hm = s.bm[tm + tid]; hs = s.bs[tm + tid]; }
-        }
-        float2 ylast = s.y[tm];
-        float vplast = s.vp[3 + tm];
-        __syncthreads();
-        if (tid < HV) {
-          s.v[tid] = hv;
-          if constexpr (MODE == 2) { s.bm[tid] = hm; s.bs[tid] = hs; }
-        }
-        if (tid == 0) {
-          s.y[0] = ylast;
-          if constexpr (MODE == 2) s.vp[3] = vplast;
-        }
-        /* the next tile's first barrier orders these writes before any read */
-      }
+    if (t0s == 0) {
+      pend = 0; pcm_off = 0;
+      q1 = (MODE == 2) && P.resample && (acc + slow >= fast);
     }
 
+    /* -- this tile's IQ has landed; start fetching the next one -- */
+    full_barrier();
+    if (tile + 1 < n_tiles) {
+      const int b2 = (tile + 1) / tiles_per_block, t2 = ((tile + 1) - b2 * tiles_per_block) * TM;
+      const uint8_t *src = iq_stream + (size_t)b2 * P.block_len + (size_t)t2 * 16;
+      load_tile_async(reinterpret_cast<const uint4 *>(src) - 3, buf ^ 1, 0, min(TM, M - t2) + 3);
+    }
+    FMD_STAMP(0)
+
+    /* -- A: /8 low-pass -- */
+    if (P.offset_tuning) decimate_tile<EX, false>(buf, tm);
+    else decimate_tile<EX, true>(buf, tm);
+    if (head) {
+      lds_barrier();
+      if (P.offset_tuning) decimate_head<false>(buf, st->tb, tm);
+      else decimate_head<true>(buf, st->tb, tm);
+    }
+    lds_barrier();
+    FMD_STAMP(1)
+    if (dbg_y) {
+      float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s;
+      for (int m = tid; m < tm; m += NT) o[m] = s.y[1 + m];
+    }
+
+    /* -- B: discriminator -- */
+    discriminate_tile<EX>(tm);
+    lds_barrier();
+    FMD_STAMP(2)
+    if (dbg_v) {
+      float *o = dbg_v + slot * M + t0s;
+      for (int m = tid; m < tm; m += NT) o[m] = s.v[HV + m];
+    }
+
+    /* -- Q + C: stereo MPX filters -- */
+    if constexpr (MODE == 2) {
+      if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>();
+      FMD_STAMP(3)
+      mpx_tile<EX, HALF>(tm);
+      lds_barrier();
+      FMD_STAMP(4)
+      carrier_tile<EX>(tm);
+      lds_barrier();
+      FMD_STAMP(5)
+    }
+
+    /* -- D: resampler outputs of this tile -- */
+    int nq;
+    if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
+    else nq = tm;
+    if (pend + nq * CH > CAPF) {
+      flush_frames<EX, CH>(pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+      pcm_off += pend;
+      pend = 0;
+      FMD_STAMP(8)
+    }
+    resample_tile<EX, MODE, HALF>(acc, nq, pend);
+    pend += nq * CH;
+    if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
+    lds_barrier();
+    FMD_STAMP(6)
+
+    /* -- roll the histories to the front of their buffers -- */
+    roll_history<MODE>(tm);
+    FMD_STAMP(7)
+
     /* -- F: end of block -> PCM -- */
-    __syncthreads();
-    flush_frames<EX, MODE>(s, P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-    if (tid == 0) lens_all[slot] = pcm_off + pend;
+    if (t0s + TM >= M) {
+      lds_barrier();
+      flush_frames<EX, CH>(pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+      if (tid == 0) lens_all[slot] = pcm_off + pend;
+      FMD_STAMP(8)
+    }
+    tm_last = tm;
+    buf ^= 1;
   }
 
   /* carried state -> HBM */
-  __syncthreads();
-  if (P.n_blocks > 0) {
-    /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
-    if (tid < 48) {
-      const int tm_last = (M % TM) ? (M % TM) : TM;
-      const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq) + 16 * tm_last;   /* 48 bytes */
-      const int j = tid >> 1, comp = tid & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
-      int sel; float sg;
-      if (P.offset_tuning) { sel = comp; sg = 1.f; }
-      else {
-        sel = comp ? sel_q<true>(p) : sel_i<true>(p);
-        sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
-      }
-      st->tb[tid] = sg * t0((float)raw[2 * j + sel]);
-    }
-    for (int i = tid; i < size; i += NT) {
-      st->br[i] = s.v[HV - size + i];
-      if constexpr (MODE == 2) {
-        st->bm[i] = s.bm[HV - size + i];
-        st->bs[i] = s.bs[HV - size + i];
-      }
-    }
-    if (tid == 0) {
-      st->pre_r = s.y[0].x;
-      st->pre_j = s.y[0].y;
-      if constexpr (MODE == 2) st->pp = s.vp[3];
-      st->de_l = s.de[0];
-      st->de_r = s.de[1];
-      st->acc = (int32_t)acc;
-    }
+  lds_barrier();
+  if (n_tiles > 0) state_out<MODE>(st, buf ^ 1, tm_last, acc);
+  FMD_STAMP(9)
+  if (dbg_prof && tid == 0) {
+    long long *o = dbg_prof + 16 * (size_t)stream;
+    for (int i = 0; i < 10; i++) o[i] = pf[i];
+    o[15] = pf_last - pf_start;
   }
+#undef FMD_STAMP
 }
 
 template <bool EX, int MODE, int HALF>
@@ -612,13 +757,16 @@ int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, v
                      static_cast<int32_t *>(lens), static_cast<DevState *>(state),
                      dbg ? static_cast<float *>(dbg->y) : nullptr,
                      dbg ? static_cast<float *>(dbg->v) : nullptr,
-                     dbg ? static_cast<float *>(dbg->mpx) : nullptr);
+                     dbg ? static_cast<float *>(dbg->mpx) : nullptr,
+                     dbg ? static_cast<long long *>(dbg->prof) : nullptr);
   return (int)hipGetLastError();
 }
 
 template <bool EX>
 int launch_math(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens, void *state,
                 const fmd_debug_taps *dbg, hipStream_t stream) {
+  /* rate_out2 <= 0: full_demod skips lp_real_f32 altogether (src/rtl_fm_player.c:781) */
+  if (!p->resample) return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
   if (p->mode == 2) {
     if (p->half == 45) return launch_one<EX, 2, 45>(p, n_streams, iq, pcm, lens, state, dbg, stream);
     return launch_one<EX, 2, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);

@@ -1,0 +1,129 @@
+// Micro-benchmarks answering design questions for the FM kernels (gfx950).
+//   hipcc --offload-arch=gfx950 -O3 -o ubench ubench.hip && ./ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+
+// 16 independent accumulators, plain v_fma_f32
+__global__ void k_fma(float *out, float a, float b) {
+  float acc[16];
+  for (int i = 0; i < 16; i++) acc[i] = threadIdx.x + i;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __builtin_fmaf(acc[i], a, b);
+  }
+  float s = 0; for (int i = 0; i < 16; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// packed: 8 x v_pk_fma_f32 = 16 FMAs
+__global__ void k_pkfma(float *out, float a, float b) {
+  f2 acc[8];
+  for (int i = 0; i < 8; i++) acc[i] = f2{(float)threadIdx.x + i, (float)i};
+  f2 av = {a, a}, bv = {b, b};
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = __builtin_elementwise_fma(acc[i], av, bv);
+  }
+  float s = 0; for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// add + fma mix like the FIR inner loop: p = x + y; acc = fma(p, t, acc)
+__global__ void k_addfma(float *out, float a, float b) {
+  float acc[8], x[8];
+  for (int i = 0; i < 8; i++) { acc[i] = threadIdx.x + i; x[i] = i * a; }
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { float p = x[i] + acc[(i + 1) & 7]; acc[i] = __builtin_fmaf(p, a, acc[i]); }
+  }
+  float s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// v_cvt_f32_ubyte throughput
+__global__ void k_cvt(float *out, unsigned w) {
+  float acc[8]; unsigned x = w + threadIdx.x;
+  for (int i = 0; i < 8; i++) acc[i] = i;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc[i] += (float)((x >> (8 * (i & 3))) & 0xff); }
+    x = x * 1664525u + 1013904223u;
+  }
+  float s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__shared__ f4 lds[4096];
+// LDS reads: mode 0 = b128 distinct contiguous, 1 = b128 broadcast (same address), 2 = b64 contiguous,
+//            3 = b32 contiguous, 4 = b96-like broadcast (use 3 of 4), 5 = b64 broadcast
+template <int MODE>
+__global__ void k_lds(float *out, int stride) {
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = f4{(float)i, 1.f, 2.f, 3.f};
+  __syncthreads();
+  float acc = 0;
+  const float *lf = (const float *)lds;
+  const f2 *l2 = (const f2 *)lds;
+  int base = (MODE == 0 || MODE == 2 || MODE == 3) ? threadIdx.x : 0;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int idx = (base + (it & 15) * 64 + i * stride) & 2047;
+      if (MODE == 0 || MODE == 1) { f4 v = lds[idx]; acc += v.x + v.w; }
+      if (MODE == 4) { f4 v = lds[idx]; acc += v.x + v.z; }
+      if (MODE == 2 || MODE == 5) { f2 v = l2[idx]; acc += v.x + v.y; }
+      if (MODE == 3) { acc += lf[idx]; }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <typename F>
+float time_kernel(F launch, int reps = 5) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  launch(); hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main() {
+  float *out; CHECK(hipMalloc(&out, 256 * 1024 * 4 * sizeof(float)));
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("device %s CUs %d clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+  const int cus = prop.multiProcessorCount;
+  for (int wpsimd : {1, 2, 4}) {
+    int threads = 64 * 4 * wpsimd;  // one block per CU
+    if (threads > 1024) continue;
+    double lane_ops = (double)cus * threads * ITERS * 16;
+    float t1 = time_kernel([&] { hipLaunchKernelGGL(k_fma, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f); });
+    float t2 = time_kernel([&] { hipLaunchKernelGGL(k_pkfma, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f); });
+    float t3 = time_kernel([&] { hipLaunchKernelGGL(k_addfma, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f); });
+    float t4 = time_kernel([&] { hipLaunchKernelGGL(k_cvt, dim3(cus), dim3(threads), 0, 0, out, 12345u); });
+    printf("waves/SIMD %d: fma %.3f ms = %.1f Tlane-FMA/s | pk_fma %.3f ms = %.1f Tlane-FMA/s | add+fma %.3f ms = %.1f Tlane-op/s | cvt+add %.3f ms = %.1f Tlane-op/s\n",
+           wpsimd, t1, lane_ops / t1 / 1e9, t2, lane_ops / t2 / 1e9, t3, lane_ops / t3 / 1e9, t4, lane_ops / t4 / 1e9);
+  }
+  for (int wpsimd : {1, 2, 4}) {
+    int threads = 64 * 4 * wpsimd;
+    double reads = (double)cus * threads * ITERS * 8;
+    float a0 = time_kernel([&] { hipLaunchKernelGGL(k_lds<0>, dim3(cus), dim3(threads), 0, 0, out, 0); });
+    float a1 = time_kernel([&] { hipLaunchKernelGGL(k_lds<1>, dim3(cus), dim3(threads), 0, 0, out, 1); });
+    float a2 = time_kernel([&] { hipLaunchKernelGGL(k_lds<2>, dim3(cus), dim3(threads), 0, 0, out, 0); });
+    float a3 = time_kernel([&] { hipLaunchKernelGGL(k_lds<3>, dim3(cus), dim3(threads), 0, 0, out, 0); });
+    float a4 = time_kernel([&] { hipLaunchKernelGGL(k_lds<4>, dim3(cus), dim3(threads), 0, 0, out, 1); });
+    float a5 = time_kernel([&] { hipLaunchKernelGGL(k_lds<5>, dim3(cus), dim3(threads), 0, 0, out, 1); });
+    // cycles per wave-instruction per CU at 2.4 GHz
+    auto cyc = [&](float ms) { return ms * 1e-3 * 2.4e9 / (reads / 64 / cus); };
+    printf("waves/SIMD %d LDS cycles per wave-instr (per CU @2.4GHz): b128 %.2f | b128 bcast %.2f | b64 %.2f | b32 %.2f | b96 bcast %.2f | b64 bcast %.2f\n",
+           wpsimd, cyc(a0), cyc(a1), cyc(a2), cyc(a3), cyc(a4), cyc(a5));
+  }
+  hipFree(out);
+  return 0;
+}
