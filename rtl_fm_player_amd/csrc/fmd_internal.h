@@ -13,9 +13,10 @@
 extern "C" {
 #endif
 
-#define FMDK_TILE 2048        /* rate_in samples per tile                       */
+#define FMDK_TILE 4096        /* rate_in samples per tile (MPX / resampler stages) */
+#define FMDK_SUB 1024         /* rate_in samples per IQ sub-tile (decimator stages) */
 #define FMDK_HIST 256         /* history slots kept in front of each FIR tile   */
-#define FMDK_FRAME_CAP 8192   /* pending resampler outputs (floats) before a flush */
+#define FMDK_FRAME_CAP 6144   /* pending resampler outputs (floats) before a flush */
 #define FMDK_THREADS 512
 
 /* Uniform launch parameters, passed by value in the kernarg segment so that

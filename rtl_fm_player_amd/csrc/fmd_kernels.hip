@@ -6,31 +6,34 @@
  * de-emphasis) is handed from tile to tile through LDS exactly as the
  * reference hands it from call to call.  HBM traffic is the algorithmic
  * minimum: the u8 IQ is read once (16 B per lane, straight into LDS with
- * global_load_lds, one tile ahead of the arithmetic), the int16 PCM is written
- * once; every intermediate (decimated IQ, discriminator output, the three MPX
- * filter outputs, resampled frames) lives in LDS.
+ * global_load_lds, one sub-tile ahead of the arithmetic), the int16 PCM is
+ * written once; every intermediate (decimated IQ, discriminator output, the
+ * MPX filter outputs, resampled frames) lives in LDS.
  *
- * Stages per tile of FMDK_TILE rate_in samples (reference src/rtl_fm_player.c):
- *   A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
- *   B  polynomial-atan2 FM discriminator             :606-685
- *   Q  block-start overwrite quirk (stereo)          :534-598
- *   C  three 90-tap MPX FIRs + 38 kHz carrier        :533-568, :472-481
- *   D  rational resampler, second FIR at emit times  :570-598 (stereo), :500-532 (mono)
- *   F  de-emphasis, f32 -> s16, PCM store            :687-735
+ * Stages (reference src/rtl_fm_player.c):
+ *   per sub-tile of FMDK_SUB rate_in samples (8 x as many IQ samples):
+ *     A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
+ *     B  polynomial-atan2 FM discriminator             :606-685
+ *   per tile of FMDK_TILE rate_in samples:
+ *     Q  block-start overwrite quirk (stereo)          :534-598
+ *     C  three 90-tap MPX FIRs + 38 kHz carrier        :533-568, :472-481
+ *     D  rational resampler, second FIR at emit times  :570-598 (stereo), :500-532 (mono)
+ *   per block:
+ *     F  de-emphasis, f32 -> s16, PCM store            :687-735
  *
  * Two arithmetic contracts (template parameter EX):
  *   exact: the reference's operation order with unfused multiply/add (this
  *          file is compiled with -ffp-contract=off) -> bit-identical PCM;
  *   fast:  same summation order with explicit fused multiply-adds and the
  *          u8 offset folded into the decimator taps -> PCM within +-1 LSB.
- * No MFMA: the path is int8/fp32 streaming work.
- *
- * Code shape: the kernel body is a small uniform control loop; each stage is a
- * separate (noinline) device function working on the one file-scope LDS
- * object, so every stage gets its own register allocation instead of one
- * 7000-instruction body whose hoisted invariants spill.  Filter taps live in
- * LDS and are read with wave-uniform addresses (broadcast): ~200 taps do not
- * fit the scalar register file.
+ * No MFMA: the path is int8/fp32 streaming work; the
+ * bound that matters is fp32 VALU issue, so the hot loops are written to keep
+ * the non-FMA instruction count and the LDS traffic per FMA low:
+ *   - stage C gives each lane 8 consecutive outputs (register blocking): the
+ *     three filters share one pair-sum, one tap read serves 8 outputs;
+ *   - decimator / resampler taps are scalar (kernarg) operands, MPX taps are
+ *     wave-uniform LDS reads;
+ *   - {L+R, L-R} histories are interleaved so the resampler reads 8-byte pairs.
  */
 #include <hip/hip_runtime.h>
 
@@ -39,34 +42,31 @@
 namespace {
 
 constexpr int TM = FMDK_TILE;
+constexpr int SUB = FMDK_SUB;
 constexpr int HV = FMDK_HIST;
 constexpr int CAPF = FMDK_FRAME_CAP;
 constexpr int NT = FMDK_THREADS;
 constexpr int NW = NT / 64;
 constexpr int DEEMPH_GROUP = 16;   /* frames per de-emphasis lane */
+static_assert(TM % SUB == 0 && TM == 8 * NT && SUB == 2 * NT, "tiling assumptions of stages A and C");
 
 constexpr float K_PI = 3.14159265f;    /* include/rtl_fm_player.h:40 */
 constexpr float K_PI_2 = 1.5707963f;   /* :41 */
 constexpr float K_PI_4 = 0.78539816f;  /* :42 */
 
-struct Ctl {               /* uniform scalars the stage functions need */
-  float swf, cwf, lambda, coef, c_i, c_q, inv_slow;
-  int size, half, slow, fast, resample, deemph, warm, offset_tuning;
-};
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(16))) Smem {
-  uint4 iq[2][TM + 4];       /* double buffer: 48 halo bytes, then 16 bytes per rate_in sample */
-  float2 y[TM + 2];          /* y[0] = last y of the previous tile, y[1+m]      */
+  uint4 iq[2][SUB + 4];      /* double buffer: 48 halo bytes, then 16 bytes per rate_in sample */
+  float2 y[SUB + 2];         /* y[0] = last y of the previous sub-tile, y[1+m]  */
   float v[HV + TM];          /* discriminator, HV history slots in front        */
-  float bm[HV + TM];         /* L+R low-pass (stereo)                           */
-  float bs[HV + TM];         /* L-R band-pass, then x carrier (stereo)          */
-  float vp[4 + TM];          /* pilot band-pass; vp[3] = previous tile's last   */
+  float2 ms[HV + TM];        /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
   float fr[CAPF];            /* resampler outputs waiting for the flush         */
-  float4 tap_mpx[128];       /* {fm[k], fp[k], fs[k], 0}: one broadcast read per k */
-  float2 tap_dec[32];        /* fast /8 low-pass: {ts_i[j], ts_q[j]}            */
-  float fb[16];              /* exact /8 low-pass half taps                     */
+  f4 tap_mpx[128];           /* {fm[k], fp[k], fs[k], 0}, zero beyond size/2    */
+  float edge[NW + 8];        /* pilot output of each wave's last lane           */
   float de[4];               /* de-emphasis state: [0..1] current, [2..3] next  */
-  Ctl ctl;
+  float pp;                  /* pilot band-pass output of the previous sample   */
+  float pp_next;
 };
 
 __shared__ Smem g_s;
@@ -80,6 +80,16 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ void full_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+/* A zero the optimiser cannot see through: indexing the kernarg tap tables with
+ * it keeps their scalar loads inside the stage that uses them (hoisted out of
+ * the tile loop they no longer fit the SGPR file and spill to VGPR lanes). */
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+/* Compiler-only fence: bounds how far LDS reads of an unrolled loop are hoisted. */
+__device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
 
 /* ---- arithmetic helpers ------------------------------------------------ */
 
@@ -134,6 +144,15 @@ __device__ __forceinline__ float carrier38(float x, float y) {
   return (x == 0.f) ? 0.f : c;
 }
 
+template <bool EX>
+__device__ __forceinline__ float carrier_of(float vp, float vq, float swf, float cwf) {
+  const float x = vp * swf;
+  float y;
+  if constexpr (EX) y = vp * cwf - vq;
+  else y = __builtin_fmaf(vp, cwf, -vq);
+  return carrier38(x, y);
+}
+
 /* src/rtl_fm_player.c:711-735 */
 __device__ __forceinline__ int16_t to_s16(float x, float coef) {
   const float t = x * coef;
@@ -143,19 +162,19 @@ __device__ __forceinline__ int16_t to_s16(float x, float coef) {
   return (int16_t)r;
 }
 
-/* ---- tile load: global -> LDS, asynchronous ------------------------------ */
+/* ---- sub-tile load: global -> LDS, asynchronous -------------------------- */
 
 /* Copies 16-byte chunks [first, n16) of src into g_s.iq[buf].  Each wave
  * instruction moves 64 lanes x 16 B to a contiguous 1 KiB of LDS
  * (global_load_lds: wave-uniform LDS base + lane * 16). */
-__device__ __noinline__ void load_tile_async(const uint4 *src, int buf, int first, int n16) {
+__device__ __forceinline__ void load_sub_async(const uint4 *src, int buf, int first, int n16) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int base = first + 64 * wave; base < n16; base += 64 * NW) {
     const int i = base + lane;
     if (i < n16) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(src + i),
-          (__attribute__((address_space(3))) void *)(&g_s.iq[buf][base]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
+                                       (__attribute__((address_space(3))) void *)(&g_s.iq[buf][base]), 16, 0,
+                                       0);
     }
   }
 }
@@ -173,11 +192,12 @@ template <bool ROT> __device__ __forceinline__ constexpr float sgn_q(int p) {
   return !ROT ? 1.f : ((p == 0 || p == 1) ? 1.f : -1.f);
 }
 
-/* Two consecutive outputs per lane: 80 raw bytes (5 x 16 B) from the LDS tile. */
+/* Two consecutive outputs per lane: 80 raw bytes (5 x 16 B) from the LDS sub-tile. */
 template <bool EX, bool ROT>
-__device__ __noinline__ void decimate_tile(int buf, int tm) {
+__device__ __forceinline__ void decimate_sub(const fmdk_params &P, int buf, int sm) {
   Smem &s = g_s;
-  for (int item = threadIdx.x; 2 * item < tm; item += NT) {
+  const int z = opaque_zero();
+  for (int item = threadIdx.x; 2 * item < sm; item += NT) {
     uint32_t d[20];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
@@ -198,7 +218,7 @@ __device__ __noinline__ void decimate_tile(int buf, int tm) {
           const float ib = sgn_i<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_i<ROT>(pb)));
           const float qa = sgn_q<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_q<ROT>(pa)));
           const float qb = sgn_q<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_q<ROT>(pb)));
-          const float fbk = s.fb[k];
+          const float fbk = P.fb[k + z];
           const float pi = (ia + ib) * fbk;
           const float pq = (qa + qb) * fbk;
           ai = (k == 0) ? pi : ai + pi;
@@ -206,17 +226,16 @@ __device__ __noinline__ void decimate_tile(int buf, int tm) {
         }
       } else {
         /* offset and 1/128 folded into signed taps: sum_j ts[j] * u[j] + c */
-        ai = s.ctl.c_i; aq = s.ctl.c_q;
+        ai = P.c_i; aq = P.c_q;
 #pragma unroll
         for (int j = 0; j < 32; j++) {
           const int js = 8 * r + j, p = j & 3;
-          const float2 tj = s.tap_dec[j];
-          ai = __builtin_fmaf(tj.x, ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
-          aq = __builtin_fmaf(tj.y, ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
+          ai = __builtin_fmaf(P.ts_i[j + z], ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
+          aq = __builtin_fmaf(P.ts_q[j + z], ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
         }
       }
       const int m = 2 * item + r;
-      if (m < tm) s.y[1 + m] = make_float2(ai, aq);
+      if (m < sm) s.y[1 + m] = make_float2(ai, aq);
     }
   }
 }
@@ -224,10 +243,10 @@ __device__ __noinline__ void decimate_tile(int buf, int tm) {
 /* First three outputs of the first block of a launch: their window reaches
  * into the carried float history lowpass_tb (src/rtl_fm_player.c:261-363). */
 template <bool ROT>
-__device__ __noinline__ void decimate_head(int buf, const float *tb, int tm) {
+__device__ __forceinline__ void decimate_head(const fmdk_params &P, int buf, const float *tb, int sm) {
   Smem &s = g_s;
   const int lane = threadIdx.x;
-  if (lane < 6 && (lane >> 1) < tm) {
+  if (lane < 6 && (lane >> 1) < sm) {
     const int m = lane >> 1, comp = lane & 1;
     const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[buf]) + 48;
     float acc = 0.f;
@@ -247,7 +266,7 @@ __device__ __noinline__ void decimate_head(int buf, const float *tb, int tm) {
         }
         pr[e] = c;
       }
-      const float prod = (pr[0] + pr[1]) * s.fb[k];
+      const float prod = (pr[0] + pr[1]) * P.fb[k];
       acc = (k == 0) ? prod : acc + prod;
     }
     float2 *yy = &s.y[1 + m];
@@ -258,9 +277,9 @@ __device__ __noinline__ void decimate_head(int buf, const float *tb, int tm) {
 /* ---- stage B: discriminator --------------------------------------------- */
 
 template <bool EX>
-__device__ __noinline__ void discriminate_tile(int tm) {
+__device__ __forceinline__ void discriminate_sub(int v_off, int sm) {
   Smem &s = g_s;
-  for (int m = threadIdx.x; m < tm; m += NT) {
+  for (int m = threadIdx.x; m < sm; m += NT) {
     const float2 p = s.y[m], c = s.y[m + 1];
     float cr, dt;
     if constexpr (EX) {
@@ -270,128 +289,141 @@ __device__ __noinline__ void discriminate_tile(int tm) {
       cr = __builtin_fmaf(p.x, c.y, -(p.y * c.x));
       dt = __builtin_fmaf(c.x, p.x, c.y * p.y);
     }
-    s.v[HV + m] = poly_atan2<EX>(cr, dt);
+    s.v[HV + v_off + m] = poly_atan2<EX>(cr, dt);
   }
 }
 
 /* ---- stage C: MPX filters at rate_in (stereo) --------------------------- */
 
-/* Four consecutive outputs per lane from a 96-float register window. */
+/* ms[m] = { sum fm[k] p[m,k],  (sum fs[k] p[m,k]) * carrier(vp[m], vp[m-1]) },
+ * vp[m] = sum fp[k] p[m,k],  p[m,k] = v[m-89+k] + v[m-k]   (:538-566).
+ * HALF == 45: every lane owns 8 consecutive outputs and walks the 45 taps in
+ * 12 chunks of 4 (taps 45..47 are zero); a chunk needs 7 aligned 16-byte window
+ * reads and 4 tap reads for 8 x 4 x (1 add + 3 FMA).  Contains two workgroup
+ * barriers (the previous lane's last pilot output comes through a shuffle, the
+ * previous wave's through LDS). */
 template <bool EX, int HALF>
-__device__ __noinline__ void mpx_tile(int tm) {
+__device__ __forceinline__ void mpx_tile(const fmdk_params &P, int tm) {
   Smem &s = g_s;
   if constexpr (HALF == 45) {
-    constexpr int R = 4;
-    for (int item = threadIdx.x; R * item < tm; item += NT) {
-      const int m0 = R * item;
-      float w[96];                       /* w[i] = v[m0 - 92 + i] */
-      const float4 *src = reinterpret_cast<const float4 *>(&s.v[HV + m0 - 92]);
+    constexpr int R = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = R * threadIdx.x;
+    float am[R], ap[R], as[R];
 #pragma unroll
-      for (int i = 0; i < 24; i++) {
-        const float4 q = src[i];
-        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
-      }
-      float am[R], ap[R], as[R];
+    for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
+    if (m0 < tm) {
+      const f4 *v4 = reinterpret_cast<const f4 *>(s.v) + ((HV + m0 - 92) >> 2);   /* w[i] = v[m0 - 92 + i] */
+#pragma unroll 2
+      for (int c = 0; c < 12; c++) {
+        const f4 L0 = v4[c], L1 = v4[c + 1], L2 = v4[c + 2], L3 = v4[c + 3];
+        const f4 H0 = v4[22 - c], H1 = v4[23 - c], H2 = v4[24 - c];
+        const float lo[16] = {L0.x, L0.y, L0.z, L0.w, L1.x, L1.y, L1.z, L1.w,
+                              L2.x, L2.y, L2.z, L2.w, L3.x, L3.y, L3.z, L3.w};   /* w[4c ..] */
+        const float hi[12] = {H0.x, H0.y, H0.z, H0.w, H1.x, H1.y, H1.z, H1.w,
+                              H2.x, H2.y, H2.z, H2.w};                           /* w[88-4c ..] */
 #pragma unroll
-      for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
+        for (int kk = 0; kk < 4; kk++) {
+          const f4 t = s.tap_mpx[4 * c + kk];
 #pragma unroll
-      for (int k = 0; k < HALF; k++) {
-        /* keep the tap reads near their use: hoisting all 45 of them costs 180 VGPRs */
-        if (k % 5 == 0) asm volatile("" ::: "memory");
-        const float4 tk = s.tap_mpx[k];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          const float p = w[r + k + 3] + w[r + 92 - k];   /* oldest + k, newest - k */
-          am[r] = mac<EX>(am[r], p, tk.x);
-          ap[r] = mac<EX>(ap[r], p, tk.y);
-          as[r] = mac<EX>(as[r], p, tk.z);
+          for (int r = 0; r < R; r++) {
+            const float p = lo[r + kk + 3] + hi[r + 4 - kk];   /* w[r+k+3] + w[r+92-k] */
+            am[r] = mac<EX>(am[r], p, t.x);
+            ap[r] = mac<EX>(ap[r], p, t.y);
+            as[r] = mac<EX>(as[r], p, t.z);
+          }
         }
       }
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (m0 + r == tm - 1) s.pp_next = ap[r];
+    }
+    if (lane == 63) s.edge[wave + 1] = ap[R - 1];
+    if (threadIdx.x == 0) s.edge[0] = s.pp;
+    const float up = __shfl_up(ap[R - 1], 1);
+    lds_barrier();
+    if (m0 < tm) {
+      float prev = lane ? up : s.edge[wave];
+      const float swf = P.swf, cwf = P.cwf;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if (m0 + r < tm) {
-          s.bm[HV + m0 + r] = am[r];
-          s.vp[4 + m0 + r] = ap[r];
-          s.bs[HV + m0 + r] = as[r];     /* multiplied by the carrier in carrier_tile */
-        }
+        if (m0 + r < tm) s.ms[HV + m0 + r] = make_float2(am[r], as[r] * carrier_of<EX>(ap[r], prev, swf, cwf));
+        prev = ap[r];
       }
     }
+    lds_barrier();
+    if (threadIdx.x == 0) s.pp = s.pp_next;
   } else {
-    const int half = s.ctl.half, size = s.ctl.size;
+    const int half = P.half, size = P.size;
+    const float swf = P.swf, cwf = P.cwf;
     for (int m = threadIdx.x; m < tm; m += NT) {
       const float *w = &s.v[HV + m - (size - 1)];
-      float am = 0.f, ap = 0.f, as = 0.f;
+      float am = 0.f, ap = 0.f, as = 0.f, aq = 0.f;   /* aq: pilot output of sample m-1, same order */
       for (int k = 0; k < half; k++) {
         const float p = w[k] + w[size - 1 - k];
-        const float4 tk = s.tap_mpx[k];
-        am = mac<EX>(am, p, tk.x);
-        ap = mac<EX>(ap, p, tk.y);
-        as = mac<EX>(as, p, tk.z);
+        const float pq = w[k - 1] + w[size - 2 - k];
+        const f4 t = s.tap_mpx[k];
+        am = mac<EX>(am, p, t.x);
+        ap = mac<EX>(ap, p, t.y);
+        as = mac<EX>(as, p, t.z);
+        aq = mac<EX>(aq, pq, t.y);
       }
-      s.bm[HV + m] = am;
-      s.vp[4 + m] = ap;
-      s.bs[HV + m] = as;
+      if (m == 0) aq = s.pp;
+      if (m == tm - 1) s.pp_next = ap;
+      s.ms[HV + m] = make_float2(am, as * carrier_of<EX>(ap, aq, swf, cwf));
     }
+    lds_barrier();
+    if (threadIdx.x == 0) s.pp = s.pp_next;
+    lds_barrier();
   }
 }
 
-template <bool EX>
-__device__ __forceinline__ float carrier_of(float vp, float vq, float swf, float cwf) {
-  const float x = vp * swf;
-  float y;
-  if constexpr (EX) y = vp * cwf - vq;
-  else y = __builtin_fmaf(vp, cwf, -vq);
-  return carrier38(x, y);
-}
-
-/* bs[m] = vs[m] * sin2atan2(vp[m] * swf, vp[m] * cwf - vp[m-1])  (:565-566) */
-template <bool EX>
-__device__ __noinline__ void carrier_tile(int tm) {
-  Smem &s = g_s;
-  const float swf = s.ctl.swf, cwf = s.ctl.cwf;
-  for (int m = threadIdx.x; m < tm; m += NT)
-    s.bs[HV + m] *= carrier_of<EX>(s.vp[4 + m], s.vp[3 + m], swf, cwf);
-}
-
-/* Symmetric FIR with the fm taps over the `size` entries ending at newest. */
+/* Symmetric fm FIR over the `2*HALF` floats ending at newest (mono, :511-529). */
 template <bool EX, int HALF>
-__device__ __forceinline__ float fir_at(const float *newest) {
+__device__ __forceinline__ float fir_mono(const fmdk_params &P, const float *newest, int z) {
   const Smem &s = g_s;
   float acc = 0.f;
   if constexpr (HALF > 0) {
     constexpr int S = 2 * HALF;
     const float *w = newest - (S - 1);
 #pragma unroll
-    for (int k = 0; k < HALF; k++) acc = mac<EX>(acc, w[k] + w[S - 1 - k], s.tap_mpx[k].x);
+    for (int k = 0; k < HALF; k++) {
+      if (k % 8 == 0) sched_fence();
+      acc = mac<EX>(acc, w[k] + w[S - 1 - k], P.fm[k + z]);
+    }
   } else {
-    const int size = s.ctl.size, half = s.ctl.half;
+    const int size = P.size, half = P.half;
     const float *w = newest - (size - 1);
     for (int k = 0; k < half; k++) acc = mac<EX>(acc, w[k] + w[size - 1 - k], s.tap_mpx[k].x);
   }
   return acc;
 }
 
-/* Two such FIRs (L+R and L-R histories) at the same instant, sharing the taps. */
+/* The two stage-2 FIRs of the stereo path at one instant (:574-591). */
 template <bool EX, int HALF>
-__device__ __forceinline__ void fir2_at(const float *nm, const float *ns, float &om, float &os) {
+__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const float2 *newest, int z, float &om,
+                                           float &os) {
   const Smem &s = g_s;
   om = 0.f; os = 0.f;
   if constexpr (HALF > 0) {
     constexpr int S = 2 * HALF;
-    const float *wm = nm - (S - 1), *ws = ns - (S - 1);
+    const float2 *w = newest - (S - 1);
 #pragma unroll
     for (int k = 0; k < HALF; k++) {
-      const float t = s.tap_mpx[k].x;
-      om = mac<EX>(om, wm[k] + wm[S - 1 - k], t);
-      os = mac<EX>(os, ws[k] + ws[S - 1 - k], t);
+      if (k % 5 == 0) sched_fence();
+      const float2 a = w[k], b = w[S - 1 - k];
+      const float t = P.fm[k + z];
+      om = mac<EX>(om, a.x + b.x, t);
+      os = mac<EX>(os, a.y + b.y, t);
     }
   } else {
-    const int size = s.ctl.size, half = s.ctl.half;
-    const float *wm = nm - (size - 1), *ws = ns - (size - 1);
+    const int size = P.size, half = P.half;
+    const float2 *w = newest - (size - 1);
     for (int k = 0; k < half; k++) {
+      const float2 a = w[k], b = w[size - 1 - k];
       const float t = s.tap_mpx[k].x;
-      om = mac<EX>(om, wm[k] + wm[size - 1 - k], t);
-      os = mac<EX>(os, ws[k] + ws[size - 1 - k], t);
+      om = mac<EX>(om, a.x + b.x, t);
+      os = mac<EX>(os, a.y + b.y, t);
     }
   }
 }
@@ -400,25 +432,22 @@ __device__ __forceinline__ void fir2_at(const float *nm, const float *ns, float 
  * when the resampler emits on sample 0 of a block, the right-channel output is
  * stored over discriminator sample 1 before that sample is read. */
 template <bool EX, int HALF>
-__device__ __noinline__ void q1_patch() {
+__device__ __forceinline__ void q1_patch(const fmdk_params &P) {
   Smem &s = g_s;
   const int lane = threadIdx.x;
   float f = 0.f;
   if (lane < 3) {
-    const int size = s.ctl.size, half = s.ctl.half;
+    const int size = P.size, half = P.half;
     const float *w = &s.v[HV - (size - 1)];
     const float *tap = reinterpret_cast<const float *>(s.tap_mpx) + lane;
     for (int k = 0; k < half; k++) f = mac<EX>(f, w[k] + w[size - 1 - k], tap[4 * k]);
   }
   const float vp = __shfl(f, 1), vs = __shfl(f, 2);
-  if (lane == 0) {
-    s.bm[HV] = f;
-    s.bs[HV] = vs * carrier_of<EX>(vp, s.vp[3], s.ctl.swf, s.ctl.cwf);
-  }
+  if (lane == 0) s.ms[HV] = make_float2(f, vs * carrier_of<EX>(vp, s.pp, P.swf, P.cwf));
   lds_barrier();
   if (lane == 0) {
     float om, os;
-    fir2_at<EX, HALF>(&s.bm[HV], &s.bs[HV], om, os);
+    fir_stereo<EX, 0>(P, &s.ms[HV], 0, om, os);
     s.v[HV + 1] = om - os;
   }
   lds_barrier();
@@ -440,20 +469,20 @@ __device__ __forceinline__ int emit_index(uint32_t acc_t, int q, uint32_t slow, 
 }
 
 template <bool EX, int MODE, int HALF>
-__device__ __noinline__ void resample_tile(uint32_t acc_t, int nq, int pend) {
+__device__ __forceinline__ void resample_tile(const fmdk_params &P, uint32_t acc_t, int nq, int pend) {
   Smem &s = g_s;
-  const uint32_t slow = (uint32_t)s.ctl.slow, fast = (uint32_t)s.ctl.fast;
-  const float inv_slow = s.ctl.inv_slow;
-  const bool rs = s.ctl.resample != 0;
+  const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
+  const float inv_slow = 1.0f / (float)P.slow;
+  const bool rs = P.resample != 0;
+  const int z = opaque_zero();
   for (int q = threadIdx.x; q < nq; q += NT) {
     const int i = rs ? emit_index(acc_t, q, slow, fast, inv_slow) : q;
     if constexpr (MODE == 2) {
       float om, os;
-      fir2_at<EX, HALF>(&s.bm[HV + i], &s.bs[HV + i], om, os);
-      s.fr[pend + 2 * q] = om + os;          /* :595 */
-      s.fr[pend + 2 * q + 1] = om - os;      /* :596 */
+      fir_stereo<EX, HALF>(P, &s.ms[HV + i], z, om, os);
+      *reinterpret_cast<float2 *>(&s.fr[pend + 2 * q]) = make_float2(om + os, om - os);   /* :595-596 */
     } else if constexpr (MODE == 1) {
-      s.fr[pend + q] = fir_at<EX, HALF>(&s.v[HV + i]);
+      s.fr[pend + q] = fir_mono<EX, HALF>(P, &s.v[HV + i], z);
     } else {
       s.fr[pend + q] = s.v[HV + i];
     }
@@ -464,21 +493,22 @@ __device__ __noinline__ void resample_tile(uint32_t acc_t, int nq, int pend) {
 
 /* De-emphasis is a first-order recurrence (:687-709).  Each lane produces
  * DEEMPH_GROUP consecutive frames of one channel; a lane whose segment does not
- * start at the first pending frame restarts the recurrence ctl.warm frames early
+ * start at the first pending frame restarts the recurrence P.warm frames early
  * from zero (lambda^warm < 1e-12, below fp32 resolution), the others continue
  * from the carried state, so the result equals the sequential evaluation. */
 template <bool EX, int CH>
-__device__ __noinline__ void flush_frames(int pend, int16_t *pcm_out, float *mpx_dbg) {
+__device__ __forceinline__ void flush_frames(const fmdk_params &P, int pend, int16_t *pcm_out,
+                                             float *mpx_dbg) {
   Smem &s = g_s;
   const int frames = pend / CH;
-  const float coef = s.ctl.coef;
+  const float coef = P.coef;
   if (mpx_dbg) {
     for (int i = threadIdx.x; i < pend; i += NT) mpx_dbg[i] = s.fr[i];
   }
-  if (s.ctl.deemph) {
+  if (P.deemph) {
     const int groups = (frames + DEEMPH_GROUP - 1) / DEEMPH_GROUP;
-    const float lam = s.ctl.lambda;
-    const int warm = s.ctl.warm;
+    const float lam = P.lambda;
+    const int warm = P.warm;
     for (int task = threadIdx.x; task < groups * CH; task += NT) {
       const int g = task / CH, c = task % CH;
       const int f_out = g * DEEMPH_GROUP;
@@ -513,24 +543,19 @@ __device__ __noinline__ void flush_frames(int pend, int16_t *pcm_out, float *mpx
 /* ---- history roll ---------------------------------------------------------- */
 
 template <int MODE>
-__device__ __noinline__ void roll_history(int tm) {
+__device__ __forceinline__ void roll_history(int tm) {
   Smem &s = g_s;
   const int tid = threadIdx.x;
-  float hv = 0.f, hm = 0.f, hs = 0.f;
+  float hv = 0.f;
+  float2 hm = make_float2(0.f, 0.f);
   if (tid < HV) {
     hv = s.v[tm + tid];
-    if constexpr (MODE == 2) { hm = s.bm[tm + tid]; hs = s.bs[tm + tid]; }
+    if constexpr (MODE == 2) hm = s.ms[tm + tid];
   }
-  const float2 ylast = s.y[tm];
-  const float vplast = s.vp[3 + tm];
   lds_barrier();
   if (tid < HV) {
     s.v[tid] = hv;
-    if constexpr (MODE == 2) { s.bm[tid] = hm; s.bs[tid] = hs; }
-  }
-  if (tid == 0) {
-    s.y[0] = ylast;
-    if constexpr (MODE == 2) s.vp[3] = vplast;
+    if constexpr (MODE == 2) s.ms[tid] = hm;
   }
   /* the next barrier orders these writes before any read */
 }
@@ -550,40 +575,30 @@ template <int MODE>
 __device__ __forceinline__ void state_in(const fmdk_params &P, const DevState *st) {
   Smem &s = g_s;
   const int tid = threadIdx.x, size = P.size;
-  for (int i = tid; i < 128; i += NT) s.tap_mpx[i] = make_float4(P.fm[i], P.fp[i], P.fs[i], 0.f);
-  if (tid < 32) s.tap_dec[tid] = make_float2(P.ts_i[tid], P.ts_q[tid]);
-  if (tid < 16) s.fb[tid] = P.fb[tid];
+  for (int i = tid; i < 128; i += NT) s.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
   for (int i = tid; i < size; i += NT) {
     s.v[HV - size + i] = st->br[i];
-    if constexpr (MODE == 2) {
-      s.bm[HV - size + i] = st->bm[i];
-      s.bs[HV - size + i] = st->bs[i];
-    }
+    if constexpr (MODE == 2) s.ms[HV - size + i] = make_float2(st->bm[i], st->bs[i]);
   }
   if (tid == 0) {
     s.y[0] = make_float2(st->pre_r, st->pre_j);
-    s.vp[3] = st->pp;
+    s.pp = st->pp;
     s.de[0] = st->de_l;
     s.de[1] = st->de_r;
-    Ctl c;
-    c.swf = P.swf; c.cwf = P.cwf; c.lambda = P.lambda; c.coef = P.coef;
-    c.c_i = P.c_i; c.c_q = P.c_q; c.inv_slow = 1.0f / (float)P.slow;
-    c.size = P.size; c.half = P.half; c.slow = P.slow; c.fast = P.fast;
-    c.resample = P.resample; c.deemph = P.deemph; c.warm = P.warm; c.offset_tuning = P.offset_tuning;
-    s.ctl = c;
   }
 }
 
 template <int MODE>
-__device__ __noinline__ void state_out(DevState *st, int last_buf, int tm_last, uint32_t acc) {
+__device__ __forceinline__ void state_out(const fmdk_params &P, DevState *st, int last_buf, int sm_last,
+                                          uint32_t acc) {
   Smem &s = g_s;
-  const int tid = threadIdx.x, size = s.ctl.size;
+  const int tid = threadIdx.x, size = P.size;
   /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
   if (tid < 48) {
-    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[last_buf]) + 16 * tm_last;   /* 48 bytes */
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[last_buf]) + 16 * sm_last;   /* 48 bytes */
     const int j = tid >> 1, comp = tid & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
     int sel; float sg;
-    if (s.ctl.offset_tuning) { sel = comp; sg = 1.f; }
+    if (P.offset_tuning) { sel = comp; sg = 1.f; }
     else {
       sel = comp ? sel_q<true>(p) : sel_i<true>(p);
       sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
@@ -593,14 +608,15 @@ __device__ __noinline__ void state_out(DevState *st, int last_buf, int tm_last, 
   for (int i = tid; i < size; i += NT) {
     st->br[i] = s.v[HV - size + i];
     if constexpr (MODE == 2) {
-      st->bm[i] = s.bm[HV - size + i];
-      st->bs[i] = s.bs[HV - size + i];
+      const float2 m = s.ms[HV - size + i];
+      st->bm[i] = m.x;
+      st->bs[i] = m.y;
     }
   }
   if (tid == 0) {
     st->pre_r = s.y[0].x;
     st->pre_j = s.y[0].y;
-    if constexpr (MODE == 2) st->pp = s.vp[3];
+    if constexpr (MODE == 2) st->pp = s.pp;
     st->de_l = s.de[0];
     st->de_r = s.de[1];
     st->acc = (int32_t)acc;
@@ -630,8 +646,8 @@ __global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, cons
   const int tid = threadIdx.x;
   const int stream = blockIdx.x;
   const int M = P.block_len >> 4;                 /* rate_in samples per block */
-  const int tiles_per_block = (M + TM - 1) / TM;
-  const int n_tiles = tiles_per_block * P.n_blocks;
+  const int spb = (M + SUB - 1) / SUB;            /* sub-tiles per block */
+  const int n_subs = spb * P.n_blocks;
   DevState *st = state_all + stream;
   const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
@@ -639,107 +655,103 @@ __global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, cons
   state_in<MODE>(P, st);
   uint32_t acc = (uint32_t)st->acc;               /* uniform */
 
-  /* first tile: chunks 3.. (the 48 halo bytes come from the float history) */
-  if (n_tiles > 0) {
-    load_tile_async(reinterpret_cast<const uint4 *>(iq_stream) - 3, 0, 3, min(TM, M) + 3);
+  /* first sub-tile: chunks 3.. (its 48 halo bytes come from the float history) */
+  if (n_subs > 0) {
+    load_sub_async(reinterpret_cast<const uint4 *>(iq_stream) - 3, 0, 3, min(SUB, M) + 3);
     if (tid < 3) s.iq[0][tid] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
   }
   FMD_STAMP(9)
 
-  int buf = 0, tm_last = 0;
-  int pend = 0, pcm_off = 0;
-  bool q1 = false;
-  for (int tile = 0; tile < n_tiles; tile++) {
-    const int b = tile / tiles_per_block, t0s = (tile - b * tiles_per_block) * TM;
-    const int tm = min(TM, M - t0s);
-    const bool head = (tile == 0);
+  int buf = 0, sm_last = 0, g = 0;               /* g: sub-tile counter over the whole launch */
+  for (int b = 0; b < P.n_blocks; b++) {
     const size_t slot = (size_t)stream * P.n_blocks + b;
     int16_t *pcm_blk = pcm_all + slot * P.pcm_stride;
     float *mpx_blk = dbg_mpx ? dbg_mpx + slot * M : nullptr;
-    if (t0s == 0) {
-      pend = 0; pcm_off = 0;
-      q1 = (MODE == 2) && P.resample && (acc + slow >= fast);
-    }
+    int pend = 0, pcm_off = 0;
+    const bool q1 = (MODE == 2) && P.resample && (acc + slow >= fast);
 
-    /* -- this tile's IQ has landed; start fetching the next one -- */
-    full_barrier();
-    if (tile + 1 < n_tiles) {
-      const int b2 = (tile + 1) / tiles_per_block, t2 = ((tile + 1) - b2 * tiles_per_block) * TM;
-      const uint8_t *src = iq_stream + (size_t)b2 * P.block_len + (size_t)t2 * 16;
-      load_tile_async(reinterpret_cast<const uint4 *>(src) - 3, buf ^ 1, 0, min(TM, M - t2) + 3);
-    }
-    FMD_STAMP(0)
+    for (int t0s = 0; t0s < M; t0s += TM) {
+      const int tm = min(TM, M - t0s);
 
-    /* -- A: /8 low-pass -- */
-    if (P.offset_tuning) decimate_tile<EX, false>(buf, tm);
-    else decimate_tile<EX, true>(buf, tm);
-    if (head) {
+      /* ---- A + B on the tile's sub-tiles ---- */
+      for (int u0 = 0; u0 < tm; u0 += SUB, g++) {
+        const int sm = min(SUB, tm - u0);
+        const bool head = (g == 0);
+        /* this sub-tile's IQ has landed; start fetching the next one */
+        full_barrier();
+        if (g + 1 < n_subs) {
+          const int b2 = (g + 1) / spb, j2 = (g + 1) - b2 * spb;
+          const uint8_t *src = iq_stream + (size_t)b2 * P.block_len + (size_t)j2 * SUB * 16;
+          load_sub_async(reinterpret_cast<const uint4 *>(src) - 3, buf ^ 1, 0, min(SUB, M - j2 * SUB) + 3);
+        }
+        FMD_STAMP(0)
+
+        if (P.offset_tuning) decimate_sub<EX, false>(P, buf, sm);
+        else decimate_sub<EX, true>(P, buf, sm);
+        if (head) {
+          lds_barrier();
+          if (P.offset_tuning) decimate_head<false>(P, buf, st->tb, sm);
+          else decimate_head<true>(P, buf, st->tb, sm);
+        }
+        lds_barrier();
+        FMD_STAMP(1)
+        if (dbg_y) {
+          float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s + u0;
+          for (int m = tid; m < sm; m += NT) o[m] = s.y[1 + m];
+        }
+
+        discriminate_sub<EX>(u0, sm);
+        const float2 ylast = s.y[sm];
+        lds_barrier();
+        if (tid == 0) s.y[0] = ylast;
+        FMD_STAMP(2)
+        if (dbg_v) {
+          float *o = dbg_v + slot * M + t0s + u0;
+          for (int m = tid; m < sm; m += NT) o[m] = s.v[HV + u0 + m];
+        }
+        sm_last = sm;
+        buf ^= 1;
+      }
+
+      /* ---- Q + C: stereo MPX filters ---- */
+      if constexpr (MODE == 2) {
+        if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>(P);
+        FMD_STAMP(3)
+        mpx_tile<EX, HALF>(P, tm);
+        FMD_STAMP(4)
+      }
+
+      /* ---- D: resampler outputs of this tile ---- */
+      int nq;
+      if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
+      else nq = tm;
+      if (pend + nq * CH > CAPF) {
+        flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+        pcm_off += pend;
+        pend = 0;
+        FMD_STAMP(8)
+      }
+      resample_tile<EX, MODE, HALF>(P, acc, nq, pend);
+      pend += nq * CH;
+      if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
       lds_barrier();
-      if (P.offset_tuning) decimate_head<false>(buf, st->tb, tm);
-      else decimate_head<true>(buf, st->tb, tm);
+      FMD_STAMP(6)
+
+      /* ---- roll the FIR histories to the front of their buffers ---- */
+      roll_history<MODE>(tm);
+      FMD_STAMP(7)
     }
+
+    /* ---- F: end of block -> PCM ---- */
     lds_barrier();
-    FMD_STAMP(1)
-    if (dbg_y) {
-      float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s;
-      for (int m = tid; m < tm; m += NT) o[m] = s.y[1 + m];
-    }
-
-    /* -- B: discriminator -- */
-    discriminate_tile<EX>(tm);
-    lds_barrier();
-    FMD_STAMP(2)
-    if (dbg_v) {
-      float *o = dbg_v + slot * M + t0s;
-      for (int m = tid; m < tm; m += NT) o[m] = s.v[HV + m];
-    }
-
-    /* -- Q + C: stereo MPX filters -- */
-    if constexpr (MODE == 2) {
-      if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>();
-      FMD_STAMP(3)
-      mpx_tile<EX, HALF>(tm);
-      lds_barrier();
-      FMD_STAMP(4)
-      carrier_tile<EX>(tm);
-      lds_barrier();
-      FMD_STAMP(5)
-    }
-
-    /* -- D: resampler outputs of this tile -- */
-    int nq;
-    if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
-    else nq = tm;
-    if (pend + nq * CH > CAPF) {
-      flush_frames<EX, CH>(pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-      pcm_off += pend;
-      pend = 0;
-      FMD_STAMP(8)
-    }
-    resample_tile<EX, MODE, HALF>(acc, nq, pend);
-    pend += nq * CH;
-    if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
-    lds_barrier();
-    FMD_STAMP(6)
-
-    /* -- roll the histories to the front of their buffers -- */
-    roll_history<MODE>(tm);
-    FMD_STAMP(7)
-
-    /* -- F: end of block -> PCM -- */
-    if (t0s + TM >= M) {
-      lds_barrier();
-      flush_frames<EX, CH>(pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-      if (tid == 0) lens_all[slot] = pcm_off + pend;
-      FMD_STAMP(8)
-    }
-    tm_last = tm;
-    buf ^= 1;
+    flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
+    if (tid == 0) lens_all[slot] = pcm_off + pend;
+    FMD_STAMP(8)
   }
 
   /* carried state -> HBM */
   lds_barrier();
-  if (n_tiles > 0) state_out<MODE>(st, buf ^ 1, tm_last, acc);
+  if (n_subs > 0) state_out<MODE>(P, st, buf ^ 1, sm_last, acc);
   FMD_STAMP(9)
   if (dbg_prof && tid == 0) {
     long long *o = dbg_prof + 16 * (size_t)stream;
