@@ -155,7 +155,10 @@ struct fmd_batch {
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   int timed;
-  void *d_state;               /* fmd_stream_state[n_streams] */
+  void *d_state[2];            /* fmd_stream_state[n_streams], ping-pong: a multi-chunk launch
+                                  reads one and writes the other                        */
+  int cur;                     /* index of the buffer holding the current state          */
+  int n_cus;
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
   size_t cap_blocks;
@@ -253,11 +256,18 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&b->ev0)) != hipSuccess || (e = hipEventCreate(&b->ev1)) != hipSuccess ||
-      (e = hipMalloc(&b->d_state, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
-      (e = hipMemset(b->d_state, 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess) {
+      (e = hipMalloc(&b->d_state[0], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
+      (e = hipMalloc(&b->d_state[1], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
+      (e = hipMemset(b->d_state[0], 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
+      (e = hipMemset(b->d_state[1], 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess) {
     rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e));
     fmd_batch_destroy(b);
     return rc;
+  }
+  {
+    hipDeviceProp_t prop;
+    b->n_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
   }
   b->ingest = (struct fmd_ingest **)calloc((size_t)n_streams, sizeof(*b->ingest));
   if (!b->ingest) { fmd_batch_destroy(b); return fail(FMD_E_NOMEM, "out of host memory"); }
@@ -269,7 +279,8 @@ void fmd_batch_destroy(fmd_batch *b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) hipStreamSynchronize(b->stream);
-  if (b->d_state) hipFree(b->d_state);
+  if (b->d_state[0]) hipFree(b->d_state[0]);
+  if (b->d_state[1]) hipFree(b->d_state[1]);
   if (b->d_iq) hipFree(b->d_iq);
   if (b->d_pcm) hipFree(b->d_pcm);
   if (b->d_lens) hipFree(b->d_lens);
@@ -296,10 +307,22 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->stream;
   fmdk_params kp = b->kp;
   kp.n_blocks = n_blocks;
+  /* Cut each stream's blocks into time chunks until the grid offers two
+   * workgroups per CU (each chunk > 0 replays warm_tiles tiles, see the kernel). */
+  kp.warm_tiles = fmdk_warm_tiles(&kp);
+  kp.n_chunks = 1;
+  if (kp.warm_tiles > 0 && !getenv("FMD_NO_TIME_SPLIT")) {
+    int want = (2 * b->n_cus + b->n_streams - 1) / b->n_streams;
+    if (want > n_blocks) want = n_blocks;
+    if (want > 1) kp.n_chunks = want;
+  }
+  const int nxt = (kp.n_chunks > 1) ? (b->cur ^ 1) : b->cur;
   HIP_TRY(hipEventRecord(b->ev0, st));
-  int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state, dbg, st);
+  int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state[b->cur],
+                      b->d_state[nxt], dbg, st);
   if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
   HIP_TRY(hipEventRecord(b->ev1, st));
+  b->cur = nxt;
   b->timed = 1;
   return FMD_OK;
 }
@@ -360,7 +383,7 @@ int fmd_batch_get_state(fmd_batch *b, int stream, fmd_stream_state *out) {
   if (!b || !out || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemcpy(out, (char *)b->d_state + sizeof(*out) * (size_t)stream, sizeof(*out),
+  HIP_TRY(hipMemcpy(out, (char *)b->d_state[b->cur] + sizeof(*out) * (size_t)stream, sizeof(*out),
                     hipMemcpyDeviceToHost));
   return FMD_OK;
 }
@@ -369,7 +392,7 @@ int fmd_batch_set_state(fmd_batch *b, int stream, const fmd_stream_state *in) {
   if (!b || !in || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemcpy((char *)b->d_state + sizeof(*in) * (size_t)stream, in, sizeof(*in),
+  HIP_TRY(hipMemcpy((char *)b->d_state[b->cur] + sizeof(*in) * (size_t)stream, in, sizeof(*in),
                     hipMemcpyHostToDevice));
   return FMD_OK;
 }
@@ -378,7 +401,7 @@ int fmd_batch_reset(fmd_batch *b) {
   if (!b) return fail(FMD_E_ARG, "NULL batch");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemset(b->d_state, 0, sizeof(fmd_stream_state) * (size_t)b->n_streams));
+  HIP_TRY(hipMemset(b->d_state[b->cur], 0, sizeof(fmd_stream_state) * (size_t)b->n_streams));
   return FMD_OK;
 }
 

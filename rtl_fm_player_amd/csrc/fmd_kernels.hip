@@ -1,10 +1,15 @@
 /*
  * fmd_kernels.hip - fused IQ -> PCM kernel for gfx950 (MI355X).
  *
- * One workgroup owns one stream and walks its blocks in time order, so every
- * piece of carried state (FIR histories, pilot sample, resampler accumulator,
- * de-emphasis) is handed from tile to tile through LDS exactly as the
- * reference hands it from call to call.  HBM traffic is the algorithmic
+ * A workgroup owns one time chunk of one stream and walks it in time order, so
+ * every piece of carried state (FIR histories, pilot sample, resampler
+ * accumulator, de-emphasis) is handed from tile to tile through LDS exactly as
+ * the reference hands it from call to call.  A stream's launch is cut into
+ * n_chunks such chunks (whole blocks) so that two workgroups fit per CU for any
+ * stream count; a chunk that does not start the launch replays warm_tiles tiles
+ * before its first block from zero state and discards their output: all
+ * histories are finite (FIRs) or contract below fp32 resolution (de-emphasis),
+ * so its first real sample sees the same state as a sequential run.  HBM traffic is the algorithmic
  * minimum: the u8 IQ is read once (16 B per lane, straight into LDS with
  * global_load_lds, one sub-tile ahead of the arithmetic), the int16 PCM is
  * written once; every intermediate (decimated IQ, discriminator output, the
@@ -88,8 +93,12 @@ __device__ __forceinline__ int opaque_zero() {
   asm volatile("s_mov_b32 %0, 0" : "=s"(z));
   return z;
 }
-/* Compiler-only fence: bounds how far LDS reads of an unrolled loop are hoisted. */
-__device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
+/* Compiler-only fence: nothing (loads, VALU) is scheduled across it, which bounds
+ * how far the LDS reads of an unrolled loop run ahead of the arithmetic. */
+__device__ __forceinline__ void sched_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 /* ---- arithmetic helpers ------------------------------------------------ */
 
@@ -314,17 +323,23 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, int tm) {
     for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
     if (m0 < tm) {
       const f4 *v4 = reinterpret_cast<const f4 *>(s.v) + ((HV + m0 - 92) >> 2);   /* w[i] = v[m0 - 92 + i] */
-#pragma unroll 2
-      for (int c = 0; c < 12; c++) {
-        const f4 L0 = v4[c], L1 = v4[c + 1], L2 = v4[c + 2], L3 = v4[c + 3];
-        const f4 H0 = v4[22 - c], H1 = v4[23 - c], H2 = v4[24 - c];
-        const float lo[16] = {L0.x, L0.y, L0.z, L0.w, L1.x, L1.y, L1.z, L1.w,
-                              L2.x, L2.y, L2.z, L2.w, L3.x, L3.y, L3.z, L3.w};   /* w[4c ..] */
-        const float hi[12] = {H0.x, H0.y, H0.z, H0.w, H1.x, H1.y, H1.z, H1.w,
-                              H2.x, H2.y, H2.z, H2.w};                           /* w[88-4c ..] */
+      /* chunk c: window w[4c .. 4c+15] and w[88-4c .. 99-4c], taps 4c .. 4c+3.
+       * Two register sets: chunk c+1 is read while chunk c is consumed. */
+      f4 wa[11], wb[11];
+      auto load_chunk = [&](f4 (&w)[11], int c) {
+        w[0] = v4[c]; w[1] = v4[c + 1]; w[2] = v4[c + 2]; w[3] = v4[c + 3];
+        w[4] = v4[22 - c]; w[5] = v4[23 - c]; w[6] = v4[24 - c];
+        w[7] = s.tap_mpx[4 * c]; w[8] = s.tap_mpx[4 * c + 1];
+        w[9] = s.tap_mpx[4 * c + 2]; w[10] = s.tap_mpx[4 * c + 3];
+      };
+      auto use_chunk = [&](const f4 (&w)[11]) {
+        const float lo[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
+                              w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
+        const float hi[12] = {w[4].x, w[4].y, w[4].z, w[4].w, w[5].x, w[5].y, w[5].z, w[5].w,
+                              w[6].x, w[6].y, w[6].z, w[6].w};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          const f4 t = s.tap_mpx[4 * c + kk];
+          const f4 t = w[7 + kk];
 #pragma unroll
           for (int r = 0; r < R; r++) {
             const float p = lo[r + kk + 3] + hi[r + 4 - kk];   /* w[r+k+3] + w[r+92-k] */
@@ -333,6 +348,16 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, int tm) {
             as[r] = mac<EX>(as[r], p, t.z);
           }
         }
+      };
+      load_chunk(wa, 0);
+#pragma unroll 1
+      for (int c = 0; c < 12; c += 2) {       /* rolled: the schedule below is the schedule */
+        load_chunk(wb, c + 1);
+        use_chunk(wa);
+        sched_fence();
+        load_chunk(wa, c + 2 < 12 ? c + 2 : 0);   /* the last refill is a harmless re-read of chunk 0 */
+        use_chunk(wb);
+        sched_fence();
       }
 #pragma unroll
       for (int r = 0; r < R; r++)
@@ -384,12 +409,34 @@ __device__ __forceinline__ float fir_mono(const fmdk_params &P, const float *new
   const Smem &s = g_s;
   float acc = 0.f;
   if constexpr (HALF > 0) {
-    constexpr int S = 2 * HALF;
+    constexpr int S = 2 * HALF, G = 16, NG = (HALF + G - 1) / G;
     const float *w = newest - (S - 1);
+    const f4 *tp = s.tap_mpx;
+    (void)z;
+    float xa[2 * G], xb[2 * G], ta[G], tb[G];
+    auto load_group = [&](float (&x)[2 * G], float (&t)[G], int g) {
 #pragma unroll
-    for (int k = 0; k < HALF; k++) {
-      if (k % 8 == 0) sched_fence();
-      acc = mac<EX>(acc, w[k] + w[S - 1 - k], P.fm[k + z]);
+      for (int i = 0; i < G; i++) {
+        const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
+        x[2 * i] = w[kc];
+        x[2 * i + 1] = w[S - 1 - kc];
+        t[i] = tp[k].x;
+      }
+    };
+    auto use_group = [&](const float (&x)[2 * G], const float (&t)[G]) {
+#pragma unroll
+      for (int i = 0; i < G; i++) acc = mac<EX>(acc, x[2 * i] + x[2 * i + 1], t[i]);
+    };
+    static_assert(NG % 2 == 0, "group pairs");
+    load_group(xa, ta, 0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+      load_group(xb, tb, g + 1);
+      use_group(xa, ta);
+      sched_fence();
+      load_group(xa, ta, g + 2 < NG ? g + 2 : 0);
+      use_group(xb, tb);
+      sched_fence();
     }
   } else {
     const int size = P.size, half = P.half;
@@ -406,15 +453,39 @@ __device__ __forceinline__ void fir_stereo(const fmdk_params &P, const float2 *n
   const Smem &s = g_s;
   om = 0.f; os = 0.f;
   if constexpr (HALF > 0) {
-    constexpr int S = 2 * HALF;
+    constexpr int S = 2 * HALF, G = 8, NG = (HALF + G - 1) / G;     /* groups of 8 taps, last one partial */
     const float2 *w = newest - (S - 1);
+    const f4 *tp = s.tap_mpx;
+    (void)z;
+    float2 xa[2 * G], xb[2 * G];
+    float ta[G], tb[G];
+    /* taps beyond HALF are zero in tap_mpx; window indices are clamped into the window */
+    auto load_group = [&](float2 (&x)[2 * G], float (&t)[G], int g) {
 #pragma unroll
-    for (int k = 0; k < HALF; k++) {
-      if (k % 5 == 0) sched_fence();
-      const float2 a = w[k], b = w[S - 1 - k];
-      const float t = P.fm[k + z];
-      om = mac<EX>(om, a.x + b.x, t);
-      os = mac<EX>(os, a.y + b.y, t);
+      for (int i = 0; i < G; i++) {
+        const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
+        x[2 * i] = w[kc];
+        x[2 * i + 1] = w[S - 1 - kc];
+        t[i] = tp[k].x;
+      }
+    };
+    auto use_group = [&](const float2 (&x)[2 * G], const float (&t)[G]) {
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        om = mac<EX>(om, x[2 * i].x + x[2 * i + 1].x, t[i]);
+        os = mac<EX>(os, x[2 * i].y + x[2 * i + 1].y, t[i]);
+      }
+    };
+    static_assert(NG % 2 == 0, "group pairs");
+    load_group(xa, ta, 0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+      load_group(xb, tb, g + 1);
+      use_group(xa, ta);
+      sched_fence();
+      load_group(xa, ta, g + 2 < NG ? g + 2 : 0);
+      use_group(xb, tb);
+      sched_fence();
     }
   } else {
     const int size = P.size, half = P.half;
@@ -498,7 +569,7 @@ __device__ __forceinline__ void resample_tile(const fmdk_params &P, uint32_t acc
  * from the carried state, so the result equals the sequential evaluation. */
 template <bool EX, int CH>
 __device__ __forceinline__ void flush_frames(const fmdk_params &P, int pend, int16_t *pcm_out,
-                                             float *mpx_dbg) {
+                                             float *mpx_dbg, bool store) {
   Smem &s = g_s;
   const int frames = pend / CH;
   const float coef = P.coef;
@@ -528,14 +599,15 @@ __device__ __forceinline__ void flush_frames(const fmdk_params &P, int pend, int
         const float t = y - x;
         if constexpr (EX) y = x + lam * t;
         else y = __builtin_fmaf(lam, t, x);
-        pcm_out[f * CH + c] = to_s16(y, coef);
+        if (store) pcm_out[f * CH + c] = to_s16(y, coef);
       }
       if (f_end == frames) s.de[2 + c] = y;
     }
     lds_barrier();
     if (threadIdx.x < CH && frames > 0) s.de[threadIdx.x] = s.de[2 + threadIdx.x];
   } else {
-    for (int i = threadIdx.x; i < pend; i += NT) pcm_out[i] = to_s16(s.fr[i], coef);
+    if (store)
+      for (int i = threadIdx.x; i < pend; i += NT) pcm_out[i] = to_s16(s.fr[i], coef);
   }
   lds_barrier();
 }
@@ -572,19 +644,20 @@ struct DevState {   /* == fmd_stream_state */
 static_assert(sizeof(DevState) == sizeof(fmd_stream_state), "state layout");
 
 template <int MODE>
-__device__ __forceinline__ void state_in(const fmdk_params &P, const DevState *st) {
+__device__ __forceinline__ void state_in(const fmdk_params &P, const DevState *st, bool carried) {
   Smem &s = g_s;
   const int tid = threadIdx.x, size = P.size;
   for (int i = tid; i < 128; i += NT) s.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
   for (int i = tid; i < size; i += NT) {
-    s.v[HV - size + i] = st->br[i];
-    if constexpr (MODE == 2) s.ms[HV - size + i] = make_float2(st->bm[i], st->bs[i]);
+    s.v[HV - size + i] = carried ? st->br[i] : 0.f;
+    if constexpr (MODE == 2)
+      s.ms[HV - size + i] = carried ? make_float2(st->bm[i], st->bs[i]) : make_float2(0.f, 0.f);
   }
   if (tid == 0) {
-    s.y[0] = make_float2(st->pre_r, st->pre_j);
-    s.pp = st->pp;
-    s.de[0] = st->de_l;
-    s.de[1] = st->de_r;
+    s.y[0] = carried ? make_float2(st->pre_r, st->pre_j) : make_float2(0.f, 0.f);
+    s.pp = carried ? st->pp : 0.f;
+    s.de[0] = carried ? st->de_l : 0.f;
+    s.de[1] = carried ? st->de_r : 0.f;
   }
 }
 
@@ -626,11 +699,12 @@ __device__ __forceinline__ void state_out(const fmdk_params &P, DevState *st, in
 /* ---- the fused kernel ----------------------------------------------------- */
 
 template <bool EX, int MODE, int HALF>
-__global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
-                                                      int16_t *__restrict__ pcm_all,
-                                                      int32_t *__restrict__ lens_all,
-                                                      DevState *__restrict__ state_all, float *dbg_y,
-                                                      float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
+__global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
+                                                         int16_t *__restrict__ pcm_all,
+                                                         int32_t *__restrict__ lens_all,
+                                                         const DevState *__restrict__ state_in_all,
+                                                         DevState *__restrict__ state_out_all, float *dbg_y,
+                                                         float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
   Smem &s = g_s;
   /* optional per-stage cycle accounting (fmd_debug_taps.prof) */
   long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -644,117 +718,138 @@ __global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, cons
   }
   constexpr int CH = (MODE == 2) ? 2 : 1;
   const int tid = threadIdx.x;
-  const int stream = blockIdx.x;
+  const int K = P.n_chunks;
+  const int stream = blockIdx.x / K, chunk = blockIdx.x - stream * K;
   const int M = P.block_len >> 4;                 /* rate_in samples per block */
-  const int spb = (M + SUB - 1) / SUB;            /* sub-tiles per block */
-  const int n_subs = spb * P.n_blocks;
-  DevState *st = state_all + stream;
-  const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
+  const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
+  const DevState *st_in = state_in_all + stream;
 
-  state_in<MODE>(P, st);
-  uint32_t acc = (uint32_t)st->acc;               /* uniform */
+  /* this workgroup's blocks, and the rate_in sample range it walks (a chunk > 0
+   * starts warm_tiles tiles early and discards what those produce) */
+  const int b_lo = (int)((long long)chunk * P.n_blocks / K);
+  const int b_hi = (int)((long long)(chunk + 1) * P.n_blocks / K);
+  const long long n_real = (long long)b_lo * M;
+  const long long n_lo = n_real - (chunk > 0 ? (long long)P.warm_tiles * TM : 0);
+  const long long n_hi = (long long)b_hi * M;
 
-  /* first sub-tile: chunks 3.. (its 48 halo bytes come from the float history) */
-  if (n_subs > 0) {
-    load_sub_async(reinterpret_cast<const uint4 *>(iq_stream) - 3, 0, 3, min(SUB, M) + 3);
-    if (tid < 3) s.iq[0][tid] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  state_in<MODE>(P, st_in, chunk == 0);
+  uint32_t acc = (uint32_t)st_in->acc;            /* uniform */
+  if (chunk > 0 && P.resample)
+    acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)n_lo * slow) % fast);
+
+  /* first sub-tile; at the start of the launch there are no 48 halo bytes in
+   * front of it: chunk 0 takes them from the float history (decimate_head), a
+   * replaying chunk starts from zero state anyway */
+  if (n_lo < n_hi) {
+    const int off = (int)(n_lo % M);
+    const bool no_halo = (n_lo == 0);
+    const uint4 *src = reinterpret_cast<const uint4 *>(iq_stream + n_lo * 16) - 3;
+    load_sub_async(src, 0, no_halo ? 3 : 0, min(SUB, M - off) + 3);
+    if (no_halo && tid < 3) s.iq[0][tid] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
   }
   FMD_STAMP(9)
 
-  int buf = 0, sm_last = 0, g = 0;               /* g: sub-tile counter over the whole launch */
-  for (int b = 0; b < P.n_blocks; b++) {
+  int buf = 0, sm_last = 0;
+  int pend = 0, pcm_off = 0;
+  bool q1 = false, head = (chunk == 0);
+  for (long long pos = n_lo; pos < n_hi;) {       /* one iteration per tile */
+    const int b = (int)(pos / M), off = (int)(pos - (long long)b * M);
+    const int tm = min(TM, M - off);
+    const bool discard = pos < n_real;
     const size_t slot = (size_t)stream * P.n_blocks + b;
     int16_t *pcm_blk = pcm_all + slot * P.pcm_stride;
-    float *mpx_blk = dbg_mpx ? dbg_mpx + slot * M : nullptr;
-    int pend = 0, pcm_off = 0;
-    const bool q1 = (MODE == 2) && P.resample && (acc + slow >= fast);
-
-    for (int t0s = 0; t0s < M; t0s += TM) {
-      const int tm = min(TM, M - t0s);
-
-      /* ---- A + B on the tile's sub-tiles ---- */
-      for (int u0 = 0; u0 < tm; u0 += SUB, g++) {
-        const int sm = min(SUB, tm - u0);
-        const bool head = (g == 0);
-        /* this sub-tile's IQ has landed; start fetching the next one */
-        full_barrier();
-        if (g + 1 < n_subs) {
-          const int b2 = (g + 1) / spb, j2 = (g + 1) - b2 * spb;
-          const uint8_t *src = iq_stream + (size_t)b2 * P.block_len + (size_t)j2 * SUB * 16;
-          load_sub_async(reinterpret_cast<const uint4 *>(src) - 3, buf ^ 1, 0, min(SUB, M - j2 * SUB) + 3);
-        }
-        FMD_STAMP(0)
-
-        if (P.offset_tuning) decimate_sub<EX, false>(P, buf, sm);
-        else decimate_sub<EX, true>(P, buf, sm);
-        if (head) {
-          lds_barrier();
-          if (P.offset_tuning) decimate_head<false>(P, buf, st->tb, sm);
-          else decimate_head<true>(P, buf, st->tb, sm);
-        }
-        lds_barrier();
-        FMD_STAMP(1)
-        if (dbg_y) {
-          float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + t0s + u0;
-          for (int m = tid; m < sm; m += NT) o[m] = s.y[1 + m];
-        }
-
-        discriminate_sub<EX>(u0, sm);
-        const float2 ylast = s.y[sm];
-        lds_barrier();
-        if (tid == 0) s.y[0] = ylast;
-        FMD_STAMP(2)
-        if (dbg_v) {
-          float *o = dbg_v + slot * M + t0s + u0;
-          for (int m = tid; m < sm; m += NT) o[m] = s.v[HV + u0 + m];
-        }
-        sm_last = sm;
-        buf ^= 1;
-      }
-
-      /* ---- Q + C: stereo MPX filters ---- */
-      if constexpr (MODE == 2) {
-        if (q1 && t0s == 0 && tm > 1) q1_patch<EX, HALF>(P);
-        FMD_STAMP(3)
-        mpx_tile<EX, HALF>(P, tm);
-        FMD_STAMP(4)
-      }
-
-      /* ---- D: resampler outputs of this tile ---- */
-      int nq;
-      if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
-      else nq = tm;
-      if (pend + nq * CH > CAPF) {
-        flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-        pcm_off += pend;
-        pend = 0;
-        FMD_STAMP(8)
-      }
-      resample_tile<EX, MODE, HALF>(P, acc, nq, pend);
-      pend += nq * CH;
-      if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
-      lds_barrier();
-      FMD_STAMP(6)
-
-      /* ---- roll the FIR histories to the front of their buffers ---- */
-      roll_history<MODE>(tm);
-      FMD_STAMP(7)
+    float *mpx_blk = (dbg_mpx && !discard) ? dbg_mpx + slot * M : nullptr;
+    if (off == 0 || pos == n_lo) {
+      pend = 0; pcm_off = 0;
+      q1 = (MODE == 2) && off == 0 && P.resample && (acc + slow >= fast);
     }
 
-    /* ---- F: end of block -> PCM ---- */
+    /* ---- A + B on the tile's sub-tiles ---- */
+    for (int u0 = 0; u0 < tm; u0 += SUB) {
+      const int sm = min(SUB, tm - u0);
+      /* this sub-tile's IQ has landed; start fetching the next one */
+      full_barrier();
+      const long long nxt = pos + u0 + sm;
+      if (nxt < n_hi) {
+        const int off2 = (int)(nxt % M);
+        load_sub_async(reinterpret_cast<const uint4 *>(iq_stream + nxt * 16) - 3, buf ^ 1, 0,
+                       min(SUB, M - off2) + 3);
+      }
+      FMD_STAMP(0)
+
+      if (P.offset_tuning) decimate_sub<EX, false>(P, buf, sm);
+      else decimate_sub<EX, true>(P, buf, sm);
+      if (head) {
+        lds_barrier();
+        if (P.offset_tuning) decimate_head<false>(P, buf, st_in->tb, sm);
+        else decimate_head<true>(P, buf, st_in->tb, sm);
+        head = false;
+      }
+      lds_barrier();
+      FMD_STAMP(1)
+      if (dbg_y && !discard) {
+        float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + off + u0;
+        for (int m = tid; m < sm; m += NT) o[m] = s.y[1 + m];
+      }
+
+      discriminate_sub<EX>(u0, sm);
+      const float2 ylast = s.y[sm];
+      lds_barrier();
+      if (tid == 0) s.y[0] = ylast;
+      FMD_STAMP(2)
+      if (dbg_v && !discard) {
+        float *o = dbg_v + slot * M + off + u0;
+        for (int m = tid; m < sm; m += NT) o[m] = s.v[HV + u0 + m];
+      }
+      sm_last = sm;
+      buf ^= 1;
+    }
+
+    /* ---- Q + C: stereo MPX filters ---- */
+    if constexpr (MODE == 2) {
+      if (q1 && off == 0 && tm > 1) q1_patch<EX, HALF>(P);
+      FMD_STAMP(3)
+      mpx_tile<EX, HALF>(P, tm);
+      FMD_STAMP(4)
+    }
+
+    /* ---- D: resampler outputs of this tile ---- */
+    int nq;
+    if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
+    else nq = tm;
+    if (pend + nq * CH > CAPF) {
+      flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr, !discard);
+      pcm_off += pend;
+      pend = 0;
+      FMD_STAMP(8)
+    }
+    resample_tile<EX, MODE, HALF>(P, acc, nq, pend);
+    pend += nq * CH;
+    if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
     lds_barrier();
-    flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr);
-    if (tid == 0) lens_all[slot] = pcm_off + pend;
-    FMD_STAMP(8)
+    FMD_STAMP(6)
+
+    /* ---- roll the FIR histories to the front of their buffers ---- */
+    roll_history<MODE>(tm);
+    FMD_STAMP(7)
+
+    /* ---- F: end of block -> PCM ---- */
+    if (off + tm == M) {
+      lds_barrier();
+      flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr, !discard);
+      if (tid == 0 && !discard) lens_all[slot] = pcm_off + pend;
+      FMD_STAMP(8)
+    }
+    pos += tm;
   }
 
-  /* carried state -> HBM */
+  /* carried state -> HBM (the chunk that ends the launch) */
   lds_barrier();
-  if (n_subs > 0) state_out<MODE>(P, st, buf ^ 1, sm_last, acc);
+  if (chunk == K - 1 && n_lo < n_hi) state_out<MODE>(P, state_out_all + stream, buf ^ 1, sm_last, acc);
   FMD_STAMP(9)
   if (dbg_prof && tid == 0) {
-    long long *o = dbg_prof + 16 * (size_t)stream;
+    long long *o = dbg_prof + 16 * (size_t)blockIdx.x;
     for (int i = 0; i < 10; i++) o[i] = pf[i];
     o[15] = pf_last - pf_start;
   }
@@ -762,11 +857,12 @@ __global__ __launch_bounds__(NT) void fmd_fused_kernel(const fmdk_params P, cons
 }
 
 template <bool EX, int MODE, int HALF>
-int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens, void *state,
-               const fmd_debug_taps *dbg, hipStream_t stream) {
-  hipLaunchKernelGGL((fmd_fused_kernel<EX, MODE, HALF>), dim3(n_streams), dim3(NT), 0, stream, *p,
-                     static_cast<const uint8_t *>(iq), static_cast<int16_t *>(pcm),
-                     static_cast<int32_t *>(lens), static_cast<DevState *>(state),
+int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens,
+               const void *state_in, void *state_out, const fmd_debug_taps *dbg, hipStream_t stream) {
+  hipLaunchKernelGGL((fmd_fused_kernel<EX, MODE, HALF>), dim3(n_streams * p->n_chunks), dim3(NT), 0, stream,
+                     *p, static_cast<const uint8_t *>(iq), static_cast<int16_t *>(pcm),
+                     static_cast<int32_t *>(lens), static_cast<const DevState *>(state_in),
+                     static_cast<DevState *>(state_out),
                      dbg ? static_cast<float *>(dbg->y) : nullptr,
                      dbg ? static_cast<float *>(dbg->v) : nullptr,
                      dbg ? static_cast<float *>(dbg->mpx) : nullptr,
@@ -775,28 +871,43 @@ int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, v
 }
 
 template <bool EX>
-int launch_math(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens, void *state,
-                const fmd_debug_taps *dbg, hipStream_t stream) {
+int launch_math(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens,
+                const void *state_in, void *state_out, const fmd_debug_taps *dbg, hipStream_t stream) {
   /* rate_out2 <= 0: full_demod skips lp_real_f32 altogether (src/rtl_fm_player.c:781) */
-  if (!p->resample) return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+  if (!p->resample) return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
   if (p->mode == 2) {
-    if (p->half == 45) return launch_one<EX, 2, 45>(p, n_streams, iq, pcm, lens, state, dbg, stream);
-    return launch_one<EX, 2, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+    if (p->half == 45) return launch_one<EX, 2, 45>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
+    return launch_one<EX, 2, 0>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
   }
   if (p->mode == 1) {
-    if (p->half == 64) return launch_one<EX, 1, 64>(p, n_streams, iq, pcm, lens, state, dbg, stream);
-    return launch_one<EX, 1, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+    if (p->half == 64) return launch_one<EX, 1, 64>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
+    return launch_one<EX, 1, 0>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
   }
-  return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state, dbg, stream);
+  return launch_one<EX, 0, 0>(p, n_streams, iq, pcm, lens, state_in, state_out, dbg, stream);
 }
 
 }  // namespace
 
 extern "C" int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq, void *d_pcm,
-                           void *d_lens, void *d_state, const fmd_debug_taps *dbg, void *hip_stream) {
+                           void *d_lens, const void *d_state_in, void *d_state_out,
+                           const fmd_debug_taps *dbg, void *hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (math == FMD_MATH_EXACT) return launch_math<true>(p, n_streams, d_iq, d_pcm, d_lens, d_state, dbg, st);
-  return launch_math<false>(p, n_streams, d_iq, d_pcm, d_lens, d_state, dbg, st);
+  if (math == FMD_MATH_EXACT)
+    return launch_math<true>(p, n_streams, d_iq, d_pcm, d_lens, d_state_in, d_state_out, dbg, st);
+  return launch_math<false>(p, n_streams, d_iq, d_pcm, d_lens, d_state_in, d_state_out, dbg, st);
+}
+
+/* FIR memories: 24 IQ + 1 (discriminator) + 2 x (size - 1) rate_in samples; the
+ * de-emphasis restart needs warm frames = warm * fast / slow rate_in samples. */
+extern "C" int fmdk_warm_tiles(const fmdk_params *p) {
+  long long need = 8 + 2LL * p->size;
+  if (p->deemph) {
+    if (p->warm >= (1 << 20)) return 0;
+    need += ((long long)p->warm + DEEMPH_GROUP) * (p->resample ? (p->fast + p->slow - 1) / p->slow : 1);
+  }
+  const long long tiles = (need + TM - 1) / TM;
+  if (tiles * TM > (p->block_len >> 4)) return 0;      /* replay must stay inside the previous block */
+  return (int)tiles;
 }
 
 extern "C" const char *fmdk_kernel_name(const fmdk_params *p, int math) {
