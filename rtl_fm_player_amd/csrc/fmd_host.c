@@ -307,14 +307,21 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->stream;
   fmdk_params kp = b->kp;
   kp.n_blocks = n_blocks;
-  /* Cut each stream's blocks into time chunks until the grid offers two
-   * workgroups per CU (each chunk > 0 replays warm_tiles tiles, see the kernel). */
+  /* Cut each stream's tiles into time chunks until the grid offers enough
+   * workers (wavefronts) per CU; each chunk > 0 replays warm_tiles tiles first
+   * (see the kernel), so keep chunks at least 8x longer than the replay. */
+  kp.n_streams = b->n_streams;
   kp.warm_tiles = fmdk_warm_tiles(&kp);
   kp.n_chunks = 1;
   if (kp.warm_tiles > 0 && !getenv("FMD_NO_TIME_SPLIT")) {
-    int want = (2 * b->n_cus + b->n_streams - 1) / b->n_streams;
-    if (want > n_blocks) want = n_blocks;
-    if (want > 1) kp.n_chunks = want;
+    const char *e_w = getenv("FMD_WORKERS_PER_CU");
+    const int per_cu = e_w ? atoi(e_w) : 8;
+    const long long m = kp.block_len >> 4, tile = fmdk_tile();
+    const long long tiles = ((m + tile - 1) / tile) * n_blocks;
+    long long want = ((long long)per_cu * b->n_cus + b->n_streams - 1) / b->n_streams;
+    const long long most = tiles / (8LL * kp.warm_tiles);
+    if (want > most) want = most;
+    if (want > 1) kp.n_chunks = (int)want;
   }
   const int nxt = (kp.n_chunks > 1) ? (b->cur ^ 1) : b->cur;
   HIP_TRY(hipEventRecord(b->ev0, st));

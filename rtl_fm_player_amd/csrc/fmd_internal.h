@@ -13,11 +13,9 @@
 extern "C" {
 #endif
 
-#define FMDK_THREADS 256
-#define FMDK_TILE (8 * FMDK_THREADS)   /* rate_in samples per tile (MPX / resampler stages) */
-#define FMDK_SUB (2 * FMDK_THREADS)    /* rate_in samples per IQ sub-tile (decimator stages) */
-#define FMDK_HIST 256         /* history slots kept in front of each FIR tile   */
-#define FMDK_FRAME_CAP 6144   /* pending resampler outputs (floats) before a flush */
+#define FMDK_TILE 512         /* rate_in samples per tile: 64 lanes x 8 outputs           */
+#define FMDK_WAVES 4          /* workers (wavefronts) per workgroup                       */
+#define FMDK_FRAME_CAP 1024   /* pending resampler outputs (floats) per worker before a flush */
 
 /* Uniform launch parameters, passed by value in the kernarg segment so that
  * tap reads with constant indices become scalar loads. */
@@ -36,8 +34,9 @@ typedef struct fmdk_params {
   int32_t block_len;      /* bytes per block                                     */
   int32_t n_blocks;
   int32_t pcm_stride;     /* int16 per (stream, block)                           */
-  int32_t n_chunks;       /* time chunks per stream (workgroups per stream)      */
-  int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first block    */
+  int32_t n_streams;
+  int32_t n_chunks;       /* time chunks (workers) per stream                    */
+  int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a
@@ -46,8 +45,9 @@ int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq,
                 void *d_lens, const void *d_state_in, void *d_state_out, const fmd_debug_taps *dbg,
                 void *hip_stream);
 /* Tiles a time chunk must replay so that every FIR history is exact and the
- * de-emphasis recurrence has converged (0 if the block is too short to split). */
+ * de-emphasis recurrence has converged (0: the launch must not be split). */
 int fmdk_warm_tiles(const fmdk_params *p);
+int fmdk_tile(void);
 /* Mangled-free kernel name as rocprofv3 prints it (prefix match). */
 const char *fmdk_kernel_name(const fmdk_params *p, int math);
 /* Static LDS bytes of the fused kernel (for DESIGN.md / diagnostics). */

@@ -1,30 +1,35 @@
 /*
  * fmd_kernels.hip - fused IQ -> PCM kernel for gfx950 (MI355X).
  *
- * A workgroup owns one time chunk of one stream and walks it in time order, so
- * every piece of carried state (FIR histories, pilot sample, resampler
- * accumulator, de-emphasis) is handed from tile to tile through LDS exactly as
- * the reference hands it from call to call.  A stream's launch is cut into
- * n_chunks such chunks (whole blocks) so that two workgroups fit per CU for any
- * stream count; a chunk that does not start the launch replays warm_tiles tiles
- * before its first block from zero state and discards their output: all
- * histories are finite (FIRs) or contract below fp32 resolution (de-emphasis),
- * so its first real sample sees the same state as a sequential run.  HBM traffic is the algorithmic
- * minimum: the u8 IQ is read once (16 B per lane, straight into LDS with
- * global_load_lds, one sub-tile ahead of the arithmetic), the int16 PCM is
- * written once; every intermediate (decimated IQ, discriminator output, the
- * MPX filter outputs, resampled frames) lives in LDS.
+ * Execution model: ONE WAVEFRONT IS ONE WORKER.  A worker owns one time chunk of
+ * one stream and walks it tile by tile (FMDK_TILE rate_in samples = 8 x as many
+ * IQ samples) through every stage of the reference's chain; the 64 lanes split
+ * each tile (8 consecutive outputs per lane).  Workers never synchronise with
+ * each other: there is no workgroup barrier in the tile loop, values cross lanes
+ * through wave shuffles or through the worker's private slice of LDS (DS
+ * operations of one wave execute in order).  A CU holds 8-12 such workers, so
+ * while one waits on LDS / HBM another issues arithmetic.
  *
- * Stages (reference src/rtl_fm_player.c):
- *   per sub-tile of FMDK_SUB rate_in samples (8 x as many IQ samples):
- *     A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
- *     B  polynomial-atan2 FM discriminator             :606-685
- *   per tile of FMDK_TILE rate_in samples:
- *     Q  block-start overwrite quirk (stereo)          :534-598
- *     C  three 90-tap MPX FIRs + 38 kHz carrier        :533-568, :472-481
- *     D  rational resampler, second FIR at emit times  :570-598 (stereo), :500-532 (mono)
- *   per block:
- *     F  de-emphasis, f32 -> s16, PCM store            :687-735
+ * A stream's launch is cut into n_chunks chunks of whole tiles so that any
+ * stream count fills the chip.  A chunk that does not start the launch replays
+ * warm_tiles tiles before its first tile from zero state and discards their
+ * output: all histories are finite (FIRs) or contract below fp32 resolution
+ * (de-emphasis), so its first real sample sees the state a sequential run has.
+ *
+ * HBM traffic is the algorithmic minimum: u8 IQ is read once (each lane loads
+ * the 176 bytes its 8 outputs need as 16-byte words, one tile ahead of use; the
+ * 48-byte overlap between neighbouring lanes is served by L1), int16 PCM is
+ * written once; decimated IQ stays in registers, discriminator / MPX filter
+ * outputs / resampled frames live in the worker's LDS slice.
+ *
+ * Stages per tile (reference src/rtl_fm_player.c):
+ *   A  u8 -> f32, j^n rotation, 32-tap /8 FIR        :195-239, :253-411
+ *   B  polynomial-atan2 FM discriminator             :606-685
+ *   Q  block-start overwrite quirk (stereo)          :534-598
+ *   C  three 90-tap MPX FIRs + 38 kHz carrier        :533-568, :472-481
+ *   D  rational resampler, second FIR at emit times  :570-598 (stereo), :500-532 (mono)
+ *   F  de-emphasis, f32 -> s16, PCM store (when the frame buffer fills or a
+ *      block ends)                                   :687-735
  *
  * Two arithmetic contracts (template parameter EX):
  *   exact: the reference's operation order with unfused multiply/add (this
@@ -32,28 +37,26 @@
  *   fast:  same summation order with explicit fused multiply-adds and the
  *          u8 offset folded into the decimator taps -> PCM within +-1 LSB.
  * No MFMA: the path is int8/fp32 streaming work; the
- * bound that matters is fp32 VALU issue, so the hot loops are written to keep
- * the non-FMA instruction count and the LDS traffic per FMA low:
- *   - stage C gives each lane 8 consecutive outputs (register blocking): the
- *     three filters share one pair-sum, one tap read serves 8 outputs;
- *   - decimator / resampler taps are scalar (kernarg) operands, MPX taps are
- *     wave-uniform LDS reads;
- *   - {L+R, L-R} histories are interleaved so the resampler reads 8-byte pairs.
+ * bound that matters is fp32 VALU issue, so the hot loops keep the non-FMA
+ * instruction count and the LDS traffic per FMA low (8 outputs per lane share
+ * one pair-sum and one tap read; scalar taps for the decimator; interleaved
+ * {L+R, L-R} history so the resampler reads 8-byte pairs).
  */
 #include <hip/hip_runtime.h>
+
+#include <cstddef>
 
 #include "fmd_internal.h"
 
 namespace {
 
-constexpr int TM = FMDK_TILE;
-constexpr int SUB = FMDK_SUB;
-constexpr int HV = FMDK_HIST;
-constexpr int CAPF = FMDK_FRAME_CAP;
-constexpr int NT = FMDK_THREADS;
-constexpr int NW = NT / 64;
-constexpr int DEEMPH_GROUP = 16;   /* frames per de-emphasis lane */
-static_assert(TM % SUB == 0 && TM == 8 * NT && SUB == 2 * NT, "tiling assumptions of stages A and C");
+constexpr int TW = FMDK_TILE;          /* rate_in samples per tile (8 per lane) */
+constexpr int WPB = FMDK_WAVES;        /* workers (waves) per workgroup */
+constexpr int NT = 64 * WPB;
+constexpr int CAPW = FMDK_FRAME_CAP;   /* pending resampler outputs per worker */
+constexpr int DEEMPH_GROUP = 16;       /* frames per de-emphasis lane */
+static_assert(TW == 512, "a tile is 64 lanes x 8 outputs");
+static_assert(CAPW / DEEMPH_GROUP <= 64, "one flush must fit one wave");
 
 constexpr float K_PI = 3.14159265f;    /* include/rtl_fm_player.h:40 */
 constexpr float K_PI_2 = 1.5707963f;   /* :41 */
@@ -61,40 +64,37 @@ constexpr float K_PI_4 = 0.78539816f;  /* :42 */
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-struct __attribute__((aligned(16))) Smem {
-  uint4 iq[2][SUB + 4];      /* double buffer: 48 halo bytes, then 16 bytes per rate_in sample */
-  float2 y[SUB + 2];         /* y[0] = last y of the previous sub-tile, y[1+m]  */
-  float v[HV + TM];          /* discriminator, HV history slots in front        */
-  float2 ms[HV + TM];        /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
-  float fr[CAPF];            /* resampler outputs waiting for the flush         */
-  f4 tap_mpx[128];           /* {fm[k], fp[k], fs[k], 0}, zero beyond size/2    */
-  float edge[NW + 8];        /* pilot output of each wave's last lane           */
-  float de[4];               /* de-emphasis state: [0..1] current, [2..3] next  */
-  float pp;                  /* pilot band-pass output of the previous sample   */
-  float pp_next;
+/* history slots in front of each FIR tile: >= size - 1, and >= 92 for the
+ * aligned window reads of the 90-tap stereo path */
+template <int HALF> constexpr int hist_of() { return HALF == 45 ? 96 : (HALF == 64 ? 128 : 256); }
+
+template <int HV>
+struct __attribute__((aligned(16))) WaveMem {
+  float v[HV + TW];          /* discriminator output, HV history slots in front   */
+  float2 ms[HV + TW];        /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
+  float fr[CAPW];            /* resampler outputs waiting for the flush           */
+  float de[4];               /* de-emphasis state: [0..1] current, [2..3] next    */
+  float pp[4];               /* scratch for the generic (runtime-size) MPX path   */
+  long long prof[12];        /* per-stage cycle sums (fmd_debug_taps.prof), [11] = last stamp */
 };
 
-__shared__ Smem g_s;
+template <int HV>
+struct __attribute__((aligned(16))) Smem {
+  f4 tap_mpx[128];           /* {fm[k], fp[k], fs[k], 0}, zero beyond size/2 */
+  f4 tap_dec[16];            /* fast /8 low-pass: ts_i[0..31], then ts_q[0..31] */
+  WaveMem<HV> w[WPB];
+};
 
-/* LDS-only workgroup barrier: does not drain outstanding global_load_lds /
- * global stores (a __syncthreads() would add s_waitcnt vmcnt(0)). */
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-/* Barrier that also waits for this wave's global_load_lds writes to land. */
-__device__ __forceinline__ void full_barrier() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 /* A zero the optimiser cannot see through: indexing the kernarg tap tables with
- * it keeps their scalar loads inside the stage that uses them (hoisted out of
- * the tile loop they no longer fit the SGPR file and spill to VGPR lanes). */
+ * it keeps their scalar loads inside the stage that uses them (hoisted to the
+ * top of the kernel they do not fit the SGPR file and spill to VGPR lanes). */
 __device__ __forceinline__ int opaque_zero() {
   int z;
   asm volatile("s_mov_b32 %0, 0" : "=s"(z));
   return z;
 }
 /* Compiler-only fence: nothing (loads, VALU) is scheduled across it, which bounds
- * how far the LDS reads of an unrolled loop run ahead of the arithmetic. */
+ * how far the LDS reads of a loop run ahead of the arithmetic. */
 __device__ __forceinline__ void sched_fence() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -171,20 +171,27 @@ __device__ __forceinline__ int16_t to_s16(float x, float coef) {
   return (int16_t)r;
 }
 
-/* ---- sub-tile load: global -> LDS, asynchronous -------------------------- */
+/* element (idx & 7) of an 8-entry register array, idx uniform or per lane */
+__device__ __forceinline__ float pick8(const float (&a)[8], int idx) {
+  float r = a[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) r = ((idx & 7) == i) ? a[i] : r;
+  return r;
+}
 
-/* Copies 16-byte chunks [first, n16) of src into g_s.iq[buf].  Each wave
- * instruction moves 64 lanes x 16 B to a contiguous 1 KiB of LDS
- * (global_load_lds: wave-uniform LDS base + lane * 16). */
-__device__ __forceinline__ void load_sub_async(const uint4 *src, int buf, int first, int n16) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int base = first + 64 * wave; base < n16; base += 64 * NW) {
-    const int i = base + lane;
-    if (i < n16) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
-                                       (__attribute__((address_space(3))) void *)(&g_s.iq[buf][base]), 16, 0,
-                                       0);
-    }
+/* ---- tile load ----------------------------------------------------------- */
+
+/* The 176 bytes (11 x 16 B) that lane's 8 outputs read: rate_in sample n covers
+ * IQ bytes [16n, 16n+16) of the stream, output m needs bytes [16m-48, 16m+16).
+ * Chunk indices are clamped into the stream (clamped words only ever feed
+ * outputs that are masked or patched). */
+__device__ __forceinline__ void load_tile(uint32_t (&d)[44], const uint4 *iq16, int n_first, int n_total) {
+#pragma unroll
+  for (int i = 0; i < 11; i++) {
+    int c = n_first - 3 + i;
+    c = c < 0 ? 0 : (c >= n_total ? n_total - 1 : c);
+    const uint4 q = iq16[c];
+    d[4 * i] = q.x; d[4 * i + 1] = q.y; d[4 * i + 2] = q.z; d[4 * i + 3] = q.w;
   }
 }
 
@@ -201,69 +208,81 @@ template <bool ROT> __device__ __forceinline__ constexpr float sgn_q(int p) {
   return !ROT ? 1.f : ((p == 0 || p == 1) ? 1.f : -1.f);
 }
 
-/* Two consecutive outputs per lane: 80 raw bytes (5 x 16 B) from the LDS sub-tile. */
+/* Eight consecutive outputs from the lane's 88 IQ samples (sample j = bytes
+ * 2j, 2j+1 of d[]); output r uses samples 8r .. 8r+31, phase = index mod 4. */
 template <bool EX, bool ROT>
-__device__ __forceinline__ void decimate_sub(const fmdk_params &P, int buf, int sm) {
-  Smem &s = g_s;
-  const int z = opaque_zero();
-  for (int item = threadIdx.x; 2 * item < sm; item += NT) {
-    uint32_t d[20];
+__device__ __forceinline__ void decimate8(const fmdk_params &P, const f4 *tap_dec, const uint32_t (&d)[44],
+                                          float (&yi)[8], float (&yq)[8]) {
+  if constexpr (EX) {
+    const int z = opaque_zero();
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const uint4 q = s.iq[buf][2 * item + i];
-      d[4 * i] = q.x; d[4 * i + 1] = q.y; d[4 * i + 2] = q.z; d[4 * i + 3] = q.w;
+    for (int r = 0; r < 8; r++) {
+      /* sum_k (c[k] + c[31-k]) * fb[k], left to right (src/rtl_fm_player.c:371-403) */
+      float ai = 0.f, aq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int ja = 8 * r + k, jb = 8 * r + 31 - k;
+        const int pa = k & 3, pb = (31 - k) & 3;
+        const float ia = sgn_i<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_i<ROT>(pa)));
+        const float ib = sgn_i<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_i<ROT>(pb)));
+        const float qa = sgn_q<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_q<ROT>(pa)));
+        const float qb = sgn_q<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_q<ROT>(pb)));
+        const float fbk = P.fb[k + z];
+        const float pi = (ia + ib) * fbk;
+        const float pq = (qa + qb) * fbk;
+        ai = (k == 0) ? pi : ai + pi;
+        aq = (k == 0) ? pq : aq + pq;
+      }
+      yi[r] = ai;
+      yq[r] = aq;
+    }
+  } else {
+    /* offset and 1/128 folded into signed taps: y = c + sum_j ts[j] * u[j], j
+     * ascending.  Sample-outer order: each byte is converted once and feeds the
+     * (up to four) outputs whose window holds it.  The 64 taps sit in registers
+     * for the duration of the stage (16 broadcast LDS reads): as scalar operands
+     * they do not fit the SGPR file next to the kernel's other uniform values. */
+    float tsi[32], tsq[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const f4 a = tap_dec[i], b = tap_dec[8 + i];
+      tsi[4 * i] = a.x; tsi[4 * i + 1] = a.y; tsi[4 * i + 2] = a.z; tsi[4 * i + 3] = a.w;
+      tsq[4 * i] = b.x; tsq[4 * i + 1] = b.y; tsq[4 * i + 2] = b.z; tsq[4 * i + 3] = b.w;
     }
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      float ai, aq;
-      if constexpr (EX) {
-        /* sum_k (c[k] + c[31-k]) * fb[k], left to right (src/rtl_fm_player.c:371-403) */
-        ai = 0.f; aq = 0.f;
+    for (int r = 0; r < 8; r++) { yi[r] = P.c_i; yq[r] = P.c_q; }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int ja = 8 * r + k, jb = 8 * r + 31 - k;     /* sample index in the 40-sample span */
-          const int pa = k & 3, pb = (31 - k) & 3;
-          const float ia = sgn_i<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_i<ROT>(pa)));
-          const float ib = sgn_i<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_i<ROT>(pb)));
-          const float qa = sgn_q<ROT>(pa) * t0(ubyte(d[ja >> 1], 2 * (ja & 1) + sel_q<ROT>(pa)));
-          const float qb = sgn_q<ROT>(pb) * t0(ubyte(d[jb >> 1], 2 * (jb & 1) + sel_q<ROT>(pb)));
-          const float fbk = P.fb[k + z];
-          const float pi = (ia + ib) * fbk;
-          const float pq = (qa + qb) * fbk;
-          ai = (k == 0) ? pi : ai + pi;
-          aq = (k == 0) ? pq : aq + pq;
-        }
-      } else {
-        /* offset and 1/128 folded into signed taps: sum_j ts[j] * u[j] + c */
-        ai = P.c_i; aq = P.c_q;
+    for (int sx = 0; sx < 88; sx++) {
+      if (sx % 8 == 0) sched_fence();           /* keep conversions next to their FMAs (register pressure) */
+      const float ub[2] = {ubyte(d[sx >> 1], 2 * (sx & 1)), ubyte(d[sx >> 1], 2 * (sx & 1) + 1)};   /* I, Q */
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-          const int js = 8 * r + j, p = j & 3;
-          ai = __builtin_fmaf(P.ts_i[j + z], ubyte(d[js >> 1], 2 * (js & 1) + sel_i<ROT>(p)), ai);
-          aq = __builtin_fmaf(P.ts_q[j + z], ubyte(d[js >> 1], 2 * (js & 1) + sel_q<ROT>(p)), aq);
+      for (int r = 0; r < 8; r++) {
+        const int j = sx - 8 * r;
+        if (j >= 0 && j < 32) {
+          const int p = j & 3;
+          yi[r] = __builtin_fmaf(tsi[j], ub[sel_i<ROT>(p)], yi[r]);
+          yq[r] = __builtin_fmaf(tsq[j], ub[sel_q<ROT>(p)], yq[r]);
         }
       }
-      const int m = 2 * item + r;
-      if (m < sm) s.y[1 + m] = make_float2(ai, aq);
     }
   }
 }
 
-/* First three outputs of the first block of a launch: their window reaches
- * into the carried float history lowpass_tb (src/rtl_fm_player.c:261-363). */
+/* First three outputs of the launch: their window reaches into the carried
+ * float history lowpass_tb (src/rtl_fm_player.c:261-363).  Lanes 0..5 compute
+ * the six values (output m = lane / 2, component = lane & 1) and hand them to
+ * lane 0, which owns outputs 0..7. */
 template <bool ROT>
-__device__ __forceinline__ void decimate_head(const fmdk_params &P, int buf, const float *tb, int sm) {
-  Smem &s = g_s;
-  const int lane = threadIdx.x;
-  if (lane < 6 && (lane >> 1) < sm) {
+__device__ __forceinline__ void decimate_head(const fmdk_params &P, const uint8_t *raw, const float *tb,
+                                              int lane, float (&yi)[8], float (&yq)[8]) {
+  float acc = 0.f;
+  if (lane < 6) {
     const int m = lane >> 1, comp = lane & 1;
-    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[buf]) + 48;
-    float acc = 0.f;
     for (int k = 0; k < 16; k++) {
       float pr[2];
       for (int e = 0; e < 2; e++) {
         const int j = e ? 31 - k : k;
-        const int g = 8 * m - 24 + j;          /* sample index within the block */
+        const int g = 8 * m - 24 + j;          /* IQ sample index from the start of the stream */
         float c;
         if (g < 0) {
           c = tb[2 * (24 + g) + comp];
@@ -278,28 +297,27 @@ __device__ __forceinline__ void decimate_head(const fmdk_params &P, int buf, con
       const float prod = (pr[0] + pr[1]) * P.fb[k];
       acc = (k == 0) ? prod : acc + prod;
     }
-    float2 *yy = &s.y[1 + m];
-    if (comp) yy->y = acc; else yy->x = acc;
+  }
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const float a = __shfl(acc, 2 * m), b = __shfl(acc, 2 * m + 1);
+    if (lane == 0) { yi[m] = a; yq[m] = b; }
   }
 }
 
 /* ---- stage B: discriminator --------------------------------------------- */
 
 template <bool EX>
-__device__ __forceinline__ void discriminate_sub(int v_off, int sm) {
-  Smem &s = g_s;
-  for (int m = threadIdx.x; m < sm; m += NT) {
-    const float2 p = s.y[m], c = s.y[m + 1];
-    float cr, dt;
-    if constexpr (EX) {
-      cr = p.x * c.y - p.y * c.x;          /* pre_r * Q - pre_j * I */
-      dt = c.x * p.x + c.y * p.y;          /* I * pre_r + Q * pre_j */
-    } else {
-      cr = __builtin_fmaf(p.x, c.y, -(p.y * c.x));
-      dt = __builtin_fmaf(c.x, p.x, c.y * p.y);
-    }
-    s.v[HV + v_off + m] = poly_atan2<EX>(cr, dt);
+__device__ __forceinline__ float discriminate(float pr, float pj, float re, float im) {
+  float cr, dt;
+  if constexpr (EX) {
+    cr = pr * im - pj * re;          /* pre_r * Q - pre_j * I */
+    dt = re * pr + im * pj;          /* I * pre_r + Q * pre_j */
+  } else {
+    cr = __builtin_fmaf(pr, im, -(pj * re));
+    dt = __builtin_fmaf(re, pr, im * pj);
   }
+  return poly_atan2<EX>(cr, dt);
 }
 
 /* ---- stage C: MPX filters at rate_in (stereo) --------------------------- */
@@ -308,41 +326,39 @@ __device__ __forceinline__ void discriminate_sub(int v_off, int sm) {
  * vp[m] = sum fp[k] p[m,k],  p[m,k] = v[m-89+k] + v[m-k]   (:538-566).
  * HALF == 45: every lane owns 8 consecutive outputs and walks the 45 taps in
  * 12 chunks of 4 (taps 45..47 are zero); a chunk needs 7 aligned 16-byte window
- * reads and 4 tap reads for 8 x 4 x (1 add + 3 FMA).  Contains two workgroup
- * barriers (the previous lane's last pilot output comes through a shuffle, the
- * previous wave's through LDS). */
-template <bool EX, int HALF>
-__device__ __forceinline__ void mpx_tile(const fmdk_params &P, int tm) {
-  Smem &s = g_s;
+ * reads and 4 tap reads for 8 x 4 x (1 add + 3 FMA).  pp is the pilot output of
+ * the sample before the tile (in), of the tile's last sample (out). */
+template <bool EX, int HALF, int HV>
+__device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w, int lane,
+                                         int tm, float &pp) {
   if constexpr (HALF == 45) {
     constexpr int R = 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = R * threadIdx.x;
+    const int m0 = R * lane;
     float am[R], ap[R], as[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
     if (m0 < tm) {
-      const f4 *v4 = reinterpret_cast<const f4 *>(s.v) + ((HV + m0 - 92) >> 2);   /* w[i] = v[m0 - 92 + i] */
-      /* chunk c: window w[4c .. 4c+15] and w[88-4c .. 99-4c], taps 4c .. 4c+3.
+      const f4 *v4 = reinterpret_cast<const f4 *>(w.v) + ((HV + m0 - 92) >> 2);   /* x[i] = v[m0 - 92 + i] */
+      /* chunk c: window x[4c .. 4c+15] and x[88-4c .. 99-4c], taps 4c .. 4c+3.
        * Two register sets: chunk c+1 is read while chunk c is consumed. */
       f4 wa[11], wb[11];
-      auto load_chunk = [&](f4 (&w)[11], int c) {
-        w[0] = v4[c]; w[1] = v4[c + 1]; w[2] = v4[c + 2]; w[3] = v4[c + 3];
-        w[4] = v4[22 - c]; w[5] = v4[23 - c]; w[6] = v4[24 - c];
-        w[7] = s.tap_mpx[4 * c]; w[8] = s.tap_mpx[4 * c + 1];
-        w[9] = s.tap_mpx[4 * c + 2]; w[10] = s.tap_mpx[4 * c + 3];
+      auto load_chunk = [&](f4 (&x)[11], int c) {
+        x[0] = v4[c]; x[1] = v4[c + 1]; x[2] = v4[c + 2]; x[3] = v4[c + 3];
+        x[4] = v4[22 - c]; x[5] = v4[23 - c]; x[6] = v4[24 - c];
+        x[7] = tap_mpx[4 * c]; x[8] = tap_mpx[4 * c + 1];
+        x[9] = tap_mpx[4 * c + 2]; x[10] = tap_mpx[4 * c + 3];
       };
-      auto use_chunk = [&](const f4 (&w)[11]) {
-        const float lo[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
-                              w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
-        const float hi[12] = {w[4].x, w[4].y, w[4].z, w[4].w, w[5].x, w[5].y, w[5].z, w[5].w,
-                              w[6].x, w[6].y, w[6].z, w[6].w};
+      auto use_chunk = [&](const f4 (&x)[11]) {
+        const float lo[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                              x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+        const float hi[12] = {x[4].x, x[4].y, x[4].z, x[4].w, x[5].x, x[5].y, x[5].z, x[5].w,
+                              x[6].x, x[6].y, x[6].z, x[6].w};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          const f4 t = w[7 + kk];
+          const f4 t = x[7 + kk];
 #pragma unroll
           for (int r = 0; r < R; r++) {
-            const float p = lo[r + kk + 3] + hi[r + 4 - kk];   /* w[r+k+3] + w[r+92-k] */
+            const float p = lo[r + kk + 3] + hi[r + 4 - kk];   /* x[r+k+3] + x[r+92-k] */
             am[r] = mac<EX>(am[r], p, t.x);
             ap[r] = mac<EX>(ap[r], p, t.y);
             as[r] = mac<EX>(as[r], p, t.z);
@@ -359,68 +375,62 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, int tm) {
         use_chunk(wb);
         sched_fence();
       }
-#pragma unroll
-      for (int r = 0; r < R; r++)
-        if (m0 + r == tm - 1) s.pp_next = ap[r];
     }
-    if (lane == 63) s.edge[wave + 1] = ap[R - 1];
-    if (threadIdx.x == 0) s.edge[0] = s.pp;
     const float up = __shfl_up(ap[R - 1], 1);
-    lds_barrier();
+    const float pp_new = __shfl(pick8(ap, tm - 1), (tm - 1) >> 3);
     if (m0 < tm) {
-      float prev = lane ? up : s.edge[wave];
+      float prev = lane ? up : pp;
       const float swf = P.swf, cwf = P.cwf;
+      float2 o[R];
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if (m0 + r < tm) s.ms[HV + m0 + r] = make_float2(am[r], as[r] * carrier_of<EX>(ap[r], prev, swf, cwf));
+        o[r] = make_float2(am[r], as[r] * carrier_of<EX>(ap[r], prev, swf, cwf));
         prev = ap[r];
       }
+      f4 *dst = reinterpret_cast<f4 *>(&w.ms[HV + m0]);
+#pragma unroll
+      for (int r = 0; r < R; r += 2) dst[r >> 1] = f4{o[r].x, o[r].y, o[r + 1].x, o[r + 1].y};
     }
-    lds_barrier();
-    if (threadIdx.x == 0) s.pp = s.pp_next;
+    pp = pp_new;
   } else {
     const int half = P.half, size = P.size;
     const float swf = P.swf, cwf = P.cwf;
-    for (int m = threadIdx.x; m < tm; m += NT) {
-      const float *w = &s.v[HV + m - (size - 1)];
+    for (int m = lane; m < tm; m += 64) {
+      const float *x = &w.v[HV + m - (size - 1)];
       float am = 0.f, ap = 0.f, as = 0.f, aq = 0.f;   /* aq: pilot output of sample m-1, same order */
       for (int k = 0; k < half; k++) {
-        const float p = w[k] + w[size - 1 - k];
-        const float pq = w[k - 1] + w[size - 2 - k];
-        const f4 t = s.tap_mpx[k];
+        const float p = x[k] + x[size - 1 - k];
+        const float pq = x[k - 1] + x[size - 2 - k];
+        const f4 t = tap_mpx[k];
         am = mac<EX>(am, p, t.x);
         ap = mac<EX>(ap, p, t.y);
         as = mac<EX>(as, p, t.z);
         aq = mac<EX>(aq, pq, t.y);
       }
-      if (m == 0) aq = s.pp;
-      if (m == tm - 1) s.pp_next = ap;
-      s.ms[HV + m] = make_float2(am, as * carrier_of<EX>(ap, aq, swf, cwf));
+      if (m == 0) aq = pp;
+      if (m == tm - 1) w.pp[0] = ap;
+      w.ms[HV + m] = make_float2(am, as * carrier_of<EX>(ap, aq, swf, cwf));
     }
-    lds_barrier();
-    if (threadIdx.x == 0) s.pp = s.pp_next;
-    lds_barrier();
+    pp = w.pp[0];
   }
 }
 
 /* Symmetric fm FIR over the `2*HALF` floats ending at newest (mono, :511-529). */
 template <bool EX, int HALF>
-__device__ __forceinline__ float fir_mono(const fmdk_params &P, const float *newest, int z) {
-  const Smem &s = g_s;
+__device__ __forceinline__ float fir_mono(const fmdk_params &P, const f4 *tap_mpx, const float *newest) {
   float acc = 0.f;
   if constexpr (HALF > 0) {
     constexpr int S = 2 * HALF, G = 16, NG = (HALF + G - 1) / G;
-    const float *w = newest - (S - 1);
-    const f4 *tp = s.tap_mpx;
-    (void)z;
+    const float *x0 = newest - (S - 1);
     float xa[2 * G], xb[2 * G], ta[G], tb[G];
+    /* taps beyond HALF are zero in tap_mpx; window indices are clamped into the window */
     auto load_group = [&](float (&x)[2 * G], float (&t)[G], int g) {
 #pragma unroll
       for (int i = 0; i < G; i++) {
         const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
-        x[2 * i] = w[kc];
-        x[2 * i + 1] = w[S - 1 - kc];
-        t[i] = tp[k].x;
+        x[2 * i] = x0[kc];
+        x[2 * i + 1] = x0[S - 1 - kc];
+        t[i] = tap_mpx[k].x;
       }
     };
     auto use_group = [&](const float (&x)[2 * G], const float (&t)[G]) {
@@ -440,33 +450,29 @@ __device__ __forceinline__ float fir_mono(const fmdk_params &P, const float *new
     }
   } else {
     const int size = P.size, half = P.half;
-    const float *w = newest - (size - 1);
-    for (int k = 0; k < half; k++) acc = mac<EX>(acc, w[k] + w[size - 1 - k], s.tap_mpx[k].x);
+    const float *x = newest - (size - 1);
+    for (int k = 0; k < half; k++) acc = mac<EX>(acc, x[k] + x[size - 1 - k], tap_mpx[k].x);
   }
   return acc;
 }
 
 /* The two stage-2 FIRs of the stereo path at one instant (:574-591). */
 template <bool EX, int HALF>
-__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const float2 *newest, int z, float &om,
-                                           float &os) {
-  const Smem &s = g_s;
+__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_mpx, const float2 *newest,
+                                           float &om, float &os) {
   om = 0.f; os = 0.f;
   if constexpr (HALF > 0) {
     constexpr int S = 2 * HALF, G = 8, NG = (HALF + G - 1) / G;     /* groups of 8 taps, last one partial */
-    const float2 *w = newest - (S - 1);
-    const f4 *tp = s.tap_mpx;
-    (void)z;
+    const float2 *x0 = newest - (S - 1);
     float2 xa[2 * G], xb[2 * G];
     float ta[G], tb[G];
-    /* taps beyond HALF are zero in tap_mpx; window indices are clamped into the window */
     auto load_group = [&](float2 (&x)[2 * G], float (&t)[G], int g) {
 #pragma unroll
       for (int i = 0; i < G; i++) {
         const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
-        x[2 * i] = w[kc];
-        x[2 * i + 1] = w[S - 1 - kc];
-        t[i] = tp[k].x;
+        x[2 * i] = x0[kc];
+        x[2 * i + 1] = x0[S - 1 - kc];
+        t[i] = tap_mpx[k].x;
       }
     };
     auto use_group = [&](const float2 (&x)[2 * G], const float (&t)[G]) {
@@ -489,10 +495,10 @@ __device__ __forceinline__ void fir_stereo(const fmdk_params &P, const float2 *n
     }
   } else {
     const int size = P.size, half = P.half;
-    const float2 *w = newest - (size - 1);
+    const float2 *x = newest - (size - 1);
     for (int k = 0; k < half; k++) {
-      const float2 a = w[k], b = w[size - 1 - k];
-      const float t = s.tap_mpx[k].x;
+      const float2 a = x[k], b = x[size - 1 - k];
+      const float t = tap_mpx[k].x;
       om = mac<EX>(om, a.x + b.x, t);
       os = mac<EX>(os, a.y + b.y, t);
     }
@@ -502,26 +508,23 @@ __device__ __forceinline__ void fir_stereo(const fmdk_params &P, const float2 *n
 /* Block-start quirk (src/rtl_fm_player.c:534-598):
  * when the resampler emits on sample 0 of a block, the right-channel output is
  * stored over discriminator sample 1 before that sample is read. */
-template <bool EX, int HALF>
-__device__ __forceinline__ void q1_patch(const fmdk_params &P) {
-  Smem &s = g_s;
-  const int lane = threadIdx.x;
+template <bool EX, int HV>
+__device__ __forceinline__ void q1_patch(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w, int lane,
+                                         float pp) {
   float f = 0.f;
   if (lane < 3) {
     const int size = P.size, half = P.half;
-    const float *w = &s.v[HV - (size - 1)];
-    const float *tap = reinterpret_cast<const float *>(s.tap_mpx) + lane;
-    for (int k = 0; k < half; k++) f = mac<EX>(f, w[k] + w[size - 1 - k], tap[4 * k]);
+    const float *x = &w.v[HV - (size - 1)];
+    const float *tap = reinterpret_cast<const float *>(tap_mpx) + lane;
+    for (int k = 0; k < half; k++) f = mac<EX>(f, x[k] + x[size - 1 - k], tap[4 * k]);
   }
   const float vp = __shfl(f, 1), vs = __shfl(f, 2);
-  if (lane == 0) s.ms[HV] = make_float2(f, vs * carrier_of<EX>(vp, s.pp, P.swf, P.cwf));
-  lds_barrier();
   if (lane == 0) {
+    w.ms[HV] = make_float2(f, vs * carrier_of<EX>(vp, pp, P.swf, P.cwf));
     float om, os;
-    fir_stereo<EX, 0>(P, &s.ms[HV], 0, om, os);
-    s.v[HV + 1] = om - os;
+    fir_stereo<EX, 0>(P, tap_mpx, &w.ms[HV], om, os);
+    w.v[HV + 1] = om - os;
   }
-  lds_barrier();
 }
 
 /* ---- stage D: resampler outputs ------------------------------------------ */
@@ -539,23 +542,22 @@ __device__ __forceinline__ int emit_index(uint32_t acc_t, int q, uint32_t slow, 
   return (int)e - 1;
 }
 
-template <bool EX, int MODE, int HALF>
-__device__ __forceinline__ void resample_tile(const fmdk_params &P, uint32_t acc_t, int nq, int pend) {
-  Smem &s = g_s;
+template <bool EX, int MODE, int HALF, int HV>
+__device__ __forceinline__ void resample_tile(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w,
+                                              int lane, uint32_t acc_t, int nq, int pend) {
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
   const float inv_slow = 1.0f / (float)P.slow;
   const bool rs = P.resample != 0;
-  const int z = opaque_zero();
-  for (int q = threadIdx.x; q < nq; q += NT) {
+  for (int q = lane; q < nq; q += 64) {
     const int i = rs ? emit_index(acc_t, q, slow, fast, inv_slow) : q;
     if constexpr (MODE == 2) {
       float om, os;
-      fir_stereo<EX, HALF>(P, &s.ms[HV + i], z, om, os);
-      *reinterpret_cast<float2 *>(&s.fr[pend + 2 * q]) = make_float2(om + os, om - os);   /* :595-596 */
+      fir_stereo<EX, HALF>(P, tap_mpx, &w.ms[HV + i], om, os);
+      *reinterpret_cast<float2 *>(&w.fr[pend + 2 * q]) = make_float2(om + os, om - os);   /* :595-596 */
     } else if constexpr (MODE == 1) {
-      s.fr[pend + q] = fir_mono<EX, HALF>(P, &s.v[HV + i], z);
+      w.fr[pend + q] = fir_mono<EX, HALF>(P, tap_mpx, &w.v[HV + i]);
     } else {
-      s.fr[pend + q] = s.v[HV + i];
+      w.fr[pend + q] = w.v[HV + i];
     }
   }
 }
@@ -567,69 +569,48 @@ __device__ __forceinline__ void resample_tile(const fmdk_params &P, uint32_t acc
  * start at the first pending frame restarts the recurrence P.warm frames early
  * from zero (lambda^warm < 1e-12, below fp32 resolution), the others continue
  * from the carried state, so the result equals the sequential evaluation. */
-template <bool EX, int CH>
-__device__ __forceinline__ void flush_frames(const fmdk_params &P, int pend, int16_t *pcm_out,
-                                             float *mpx_dbg, bool store) {
-  Smem &s = g_s;
+template <bool EX, int CH, int HV>
+__device__ __forceinline__ void flush_frames(const fmdk_params &P, WaveMem<HV> &w, int lane, int pend,
+                                             int16_t *pcm_out, float *mpx_dbg, bool store) {
   const int frames = pend / CH;
   const float coef = P.coef;
   if (mpx_dbg) {
-    for (int i = threadIdx.x; i < pend; i += NT) mpx_dbg[i] = s.fr[i];
+    for (int i = lane; i < pend; i += 64) mpx_dbg[i] = w.fr[i];
   }
   if (P.deemph) {
     const int groups = (frames + DEEMPH_GROUP - 1) / DEEMPH_GROUP;
     const float lam = P.lambda;
     const int warm = P.warm;
-    for (int task = threadIdx.x; task < groups * CH; task += NT) {
-      const int g = task / CH, c = task % CH;
+    float ylast = 0.f;
+    bool have_last = false;
+    if (lane < groups * CH) {
+      const int g = lane / CH, c = lane % CH;
       const int f_out = g * DEEMPH_GROUP;
       int f = f_out - warm;
       float y = 0.f;
-      if (f <= 0) { f = 0; y = s.de[c]; }
+      if (f <= 0) { f = 0; y = w.de[c]; }
       const int f_end = min(f_out + DEEMPH_GROUP, frames);
 #pragma unroll 4
       for (; f < f_out; f++) {             /* warm-up, nothing stored */
-        const float x = s.fr[f * CH + c];
+        const float x = w.fr[f * CH + c];
         const float t = y - x;
         if constexpr (EX) y = x + lam * t;
         else y = __builtin_fmaf(lam, t, x);
       }
       for (; f < f_end; f++) {
-        const float x = s.fr[f * CH + c];
+        const float x = w.fr[f * CH + c];
         const float t = y - x;
         if constexpr (EX) y = x + lam * t;
         else y = __builtin_fmaf(lam, t, x);
         if (store) pcm_out[f * CH + c] = to_s16(y, coef);
       }
-      if (f_end == frames) s.de[2 + c] = y;
+      ylast = y;
+      have_last = (f_end == frames);
     }
-    lds_barrier();
-    if (threadIdx.x < CH && frames > 0) s.de[threadIdx.x] = s.de[2 + threadIdx.x];
-  } else {
-    if (store)
-      for (int i = threadIdx.x; i < pend; i += NT) pcm_out[i] = to_s16(s.fr[i], coef);
+    if (have_last) w.de[lane % CH] = ylast;      /* all lanes have read de[] above (same wave) */
+  } else if (store) {
+    for (int i = lane; i < pend; i += 64) pcm_out[i] = to_s16(w.fr[i], coef);
   }
-  lds_barrier();
-}
-
-/* ---- history roll ---------------------------------------------------------- */
-
-template <int MODE>
-__device__ __forceinline__ void roll_history(int tm) {
-  Smem &s = g_s;
-  const int tid = threadIdx.x;
-  float hv = 0.f;
-  float2 hm = make_float2(0.f, 0.f);
-  if (tid < HV) {
-    hv = s.v[tm + tid];
-    if constexpr (MODE == 2) hm = s.ms[tm + tid];
-  }
-  lds_barrier();
-  if (tid < HV) {
-    s.v[tid] = hv;
-    if constexpr (MODE == 2) s.ms[tid] = hm;
-  }
-  /* the next barrier orders these writes before any read */
 }
 
 /* ---- carried state in HBM ------------------------------------------------- */
@@ -643,174 +624,168 @@ struct DevState {   /* == fmd_stream_state */
 };
 static_assert(sizeof(DevState) == sizeof(fmd_stream_state), "state layout");
 
-template <int MODE>
-__device__ __forceinline__ void state_in(const fmdk_params &P, const DevState *st, bool carried) {
-  Smem &s = g_s;
-  const int tid = threadIdx.x, size = P.size;
-  for (int i = tid; i < 128; i += NT) s.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
-  for (int i = tid; i < size; i += NT) {
-    s.v[HV - size + i] = carried ? st->br[i] : 0.f;
-    if constexpr (MODE == 2)
-      s.ms[HV - size + i] = carried ? make_float2(st->bm[i], st->bs[i]) : make_float2(0.f, 0.f);
-  }
-  if (tid == 0) {
-    s.y[0] = carried ? make_float2(st->pre_r, st->pre_j) : make_float2(0.f, 0.f);
-    s.pp = carried ? st->pp : 0.f;
-    s.de[0] = carried ? st->de_l : 0.f;
-    s.de[1] = carried ? st->de_r : 0.f;
-  }
-}
-
-template <int MODE>
-__device__ __forceinline__ void state_out(const fmdk_params &P, DevState *st, int last_buf, int sm_last,
-                                          uint32_t acc) {
-  Smem &s = g_s;
-  const int tid = threadIdx.x, size = P.size;
-  /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
-  if (tid < 48) {
-    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s.iq[last_buf]) + 16 * sm_last;   /* 48 bytes */
-    const int j = tid >> 1, comp = tid & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
-    int sel; float sg;
-    if (P.offset_tuning) { sel = comp; sg = 1.f; }
-    else {
-      sel = comp ? sel_q<true>(p) : sel_i<true>(p);
-      sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
-    }
-    st->tb[tid] = sg * t0((float)raw[2 * j + sel]);
-  }
-  for (int i = tid; i < size; i += NT) {
-    st->br[i] = s.v[HV - size + i];
-    if constexpr (MODE == 2) {
-      const float2 m = s.ms[HV - size + i];
-      st->bm[i] = m.x;
-      st->bs[i] = m.y;
-    }
-  }
-  if (tid == 0) {
-    st->pre_r = s.y[0].x;
-    st->pre_j = s.y[0].y;
-    if constexpr (MODE == 2) st->pp = s.pp;
-    st->de_l = s.de[0];
-    st->de_r = s.de[1];
-    st->acc = (int32_t)acc;
-  }
-}
-
 /* ---- the fused kernel ----------------------------------------------------- */
 
 template <bool EX, int MODE, int HALF>
 __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, const uint8_t *__restrict__ iq_all,
-                                                         int16_t *__restrict__ pcm_all,
-                                                         int32_t *__restrict__ lens_all,
-                                                         const DevState *__restrict__ state_in_all,
-                                                         DevState *__restrict__ state_out_all, float *dbg_y,
-                                                         float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
-  Smem &s = g_s;
-  /* optional per-stage cycle accounting (fmd_debug_taps.prof) */
-  long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long pf_last = 0, pf_start = 0;
-  if (dbg_prof) pf_start = pf_last = clock64();
-#define FMD_STAMP(i)                                   \
-  if (dbg_prof) {                                      \
-    const long long now_ = clock64();                  \
-    pf[i] += now_ - pf_last;                           \
-    pf_last = now_;                                    \
-  }
+                                                      int16_t *__restrict__ pcm_all,
+                                                      int32_t *__restrict__ lens_all,
+                                                      const DevState *__restrict__ state_in_all,
+                                                      DevState *__restrict__ state_out_all, float *dbg_y,
+                                                      float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
+  constexpr int HV = hist_of<HALF>();
   constexpr int CH = (MODE == 2) ? 2 : 1;
-  const int tid = threadIdx.x;
+  __shared__ Smem<HV> sm;
+  for (int i = threadIdx.x; i < 128; i += NT) sm.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
+  if (threadIdx.x < 16) {
+    const float *t = (threadIdx.x < 8 ? P.ts_i : P.ts_q) + 4 * (threadIdx.x & 7);
+    sm.tap_dec[threadIdx.x] = f4{t[0], t[1], t[2], t[3]};
+  }
+  __syncthreads();                                /* the only workgroup barrier */
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = P.n_chunks;
-  const int stream = blockIdx.x / K, chunk = blockIdx.x - stream * K;
+  const int unit = blockIdx.x * WPB + wave;
+  if (unit >= P.n_streams * K) return;
+  const int stream = unit / K, chunk = unit - stream * K;
+  WaveMem<HV> &w = sm.w[wave];
+  const f4 *tap_mpx = sm.tap_mpx;
+
+  /* optional per-stage cycle accounting (fmd_debug_taps.prof): lane 0 keeps the
+   * sums in the worker's LDS slice (registers would be live across every stage) */
+  if (dbg_prof && lane == 0) {
+    for (int i = 0; i < 11; i++) w.prof[i] = 0;
+    w.prof[11] = w.prof[10] = clock64();
+  }
+#define FMD_STAMP(i)                                   \
+  if (dbg_prof && lane == 0) {                         \
+    const long long now_ = clock64();                  \
+    w.prof[i] += now_ - w.prof[11];                    \
+    w.prof[11] = now_;                                 \
+  }
+
   const int M = P.block_len >> 4;                 /* rate_in samples per block */
+  const int tpb = (M + TW - 1) / TW;              /* tiles per block */
+  const int T = tpb * P.n_blocks;                 /* tiles per stream */
+  const int n_total = M * P.n_blocks;             /* rate_in samples (= 16-byte IQ words) per stream */
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
   const uint8_t *iq_stream = iq_all + (size_t)stream * P.n_blocks * P.block_len;
+  const uint4 *iq16 = reinterpret_cast<const uint4 *>(iq_stream);
   const DevState *st_in = state_in_all + stream;
+  const int size = P.size;
 
-  /* this workgroup's blocks, and the rate_in sample range it walks (a chunk > 0
-   * starts warm_tiles tiles early and discards what those produce) */
-  const int b_lo = (int)((long long)chunk * P.n_blocks / K);
-  const int b_hi = (int)((long long)(chunk + 1) * P.n_blocks / K);
-  const long long n_real = (long long)b_lo * M;
-  const long long n_lo = n_real - (chunk > 0 ? (long long)P.warm_tiles * TM : 0);
-  const long long n_hi = (long long)b_hi * M;
+  /* this worker's tiles; a chunk > 0 starts warm_tiles tiles early and discards
+   * what those produce */
+  const int t_lo = (int)((long long)chunk * T / K), t_hi = (int)((long long)(chunk + 1) * T / K);
+  const int g_first = chunk > 0 ? t_lo - P.warm_tiles : 0;
 
-  state_in<MODE>(P, st_in, chunk == 0);
-  uint32_t acc = (uint32_t)st_in->acc;            /* uniform */
-  if (chunk > 0 && P.resample)
-    acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)n_lo * slow) % fast);
+  /* carried state (chunk 0) or zero state (replaying chunks) */
+  const bool carried = (chunk == 0);
+  for (int i = lane; i < size; i += 64) {
+    w.v[HV - size + i] = carried ? st_in->br[i] : 0.f;
+    if constexpr (MODE == 2)
+      w.ms[HV - size + i] = carried ? make_float2(st_in->bm[i], st_in->bs[i]) : make_float2(0.f, 0.f);
+  }
+  if (lane == 0) {
+    w.de[0] = carried ? st_in->de_l : 0.f;
+    w.de[1] = carried ? st_in->de_r : 0.f;
+  }
+  float ycr = carried ? st_in->pre_r : 0.f, ycj = carried ? st_in->pre_j : 0.f;   /* last decimated sample */
+  float pp = carried ? st_in->pp : 0.f;                                          /* last pilot output */
+  uint32_t acc = (uint32_t)st_in->acc;
+  {
+    const int b0 = g_first / tpb;
+    const long long n0 = (long long)b0 * M + (long long)(g_first - b0 * tpb) * TW;
+    if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)n0 * slow) % fast);
+  }
 
-  /* first sub-tile; at the start of the launch there are no 48 halo bytes in
-   * front of it: chunk 0 takes them from the float history (decimate_head), a
-   * replaying chunk starts from zero state anyway */
-  if (n_lo < n_hi) {
-    const int off = (int)(n_lo % M);
-    const bool no_halo = (n_lo == 0);
-    const uint4 *src = reinterpret_cast<const uint4 *>(iq_stream + n_lo * 16) - 3;
-    load_sub_async(src, 0, no_halo ? 3 : 0, min(SUB, M - off) + 3);
-    if (no_halo && tid < 3) s.iq[0][tid] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  uint32_t d[44];
+  if (g_first < t_hi) {
+    const int b0 = g_first / tpb;
+    load_tile(d, iq16, b0 * M + (g_first - b0 * tpb) * TW + 8 * lane, n_total);
   }
   FMD_STAMP(9)
 
-  int buf = 0, sm_last = 0;
-  int pend = 0, pcm_off = 0;
-  bool q1 = false, head = (chunk == 0);
-  for (long long pos = n_lo; pos < n_hi;) {       /* one iteration per tile */
-    const int b = (int)(pos / M), off = (int)(pos - (long long)b * M);
-    const int tm = min(TM, M - off);
-    const bool discard = pos < n_real;
+  int pend = 0, pcm_off = 0, tm_last = 0, n_last = 0;
+  bool q1 = false;
+  for (int g = g_first; g < t_hi; g++) {
+    const int b = g / tpb, off = (g - b * tpb) * TW;
+    const int tm = min(TW, M - off);
+    const int n_tile = b * M + off;               /* stream sample index of the tile's first sample */
+    const bool discard = g < t_lo;
     const size_t slot = (size_t)stream * P.n_blocks + b;
     int16_t *pcm_blk = pcm_all + slot * P.pcm_stride;
     float *mpx_blk = (dbg_mpx && !discard) ? dbg_mpx + slot * M : nullptr;
-    if (off == 0 || pos == n_lo) {
+    const int m0 = 8 * lane;
+
+    if (off == 0) {
       pend = 0; pcm_off = 0;
-      q1 = (MODE == 2) && off == 0 && P.resample && (acc + slow >= fast);
+      q1 = (MODE == 2) && P.resample && (acc + slow >= fast);
+    } else if (g == t_lo && chunk > 0) {
+      /* first real tile in the middle of a block: settle the de-emphasis state on
+       * what the replay produced, then continue the block's PCM where a
+       * sequential run would be: CH x (emits before `off` in this block) */
+      flush_frames<EX, CH, HV>(P, w, lane, pend, pcm_blk, nullptr, false);
+      pend = 0;
+      unsigned long long a0 = (unsigned long long)st_in->acc;
+      if (P.resample) {
+        a0 = (a0 + (unsigned long long)b * M * slow) % fast;
+        pcm_off = CH * (int)((a0 + (unsigned long long)off * slow) / fast);
+      } else {
+        pcm_off = CH * off;
+      }
     }
 
-    /* ---- A + B on the tile's sub-tiles ---- */
-    for (int u0 = 0; u0 < tm; u0 += SUB) {
-      const int sm = min(SUB, tm - u0);
-      /* this sub-tile's IQ has landed; start fetching the next one */
-      full_barrier();
-      const long long nxt = pos + u0 + sm;
-      if (nxt < n_hi) {
-        const int off2 = (int)(nxt % M);
-        load_sub_async(reinterpret_cast<const uint4 *>(iq_stream + nxt * 16) - 3, buf ^ 1, 0,
-                       min(SUB, M - off2) + 3);
-      }
-      FMD_STAMP(0)
+    /* ---- A: /8 low-pass, 8 outputs per lane, straight from registers ---- */
+    float yi[8], yq[8];
+    if (P.offset_tuning) decimate8<EX, false>(P, sm.tap_dec, d, yi, yq);
+    else decimate8<EX, true>(P, sm.tap_dec, d, yi, yq);
+    if (n_tile == 0 && chunk == 0) {
+      if (P.offset_tuning) decimate_head<false>(P, iq_stream, st_in->tb, lane, yi, yq);
+      else decimate_head<true>(P, iq_stream, st_in->tb, lane, yi, yq);
+    }
+    /* next tile's IQ: in flight while the rest of this tile is computed */
+    if (g + 1 < t_hi) {
+      const int b2 = (g + 1) / tpb;
+      load_tile(d, iq16, b2 * M + ((g + 1) - b2 * tpb) * TW + m0, n_total);
+    }
+    FMD_STAMP(1)
+    if (dbg_y && !discard) {
+      float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + off + m0;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        if (m0 + r < tm) o[r] = make_float2(yi[r], yq[r]);
+    }
 
-      if (P.offset_tuning) decimate_sub<EX, false>(P, buf, sm);
-      else decimate_sub<EX, true>(P, buf, sm);
-      if (head) {
-        lds_barrier();
-        if (P.offset_tuning) decimate_head<false>(P, buf, st_in->tb, sm);
-        else decimate_head<true>(P, buf, st_in->tb, sm);
-        head = false;
+    /* ---- B: discriminator; the sample before the lane's first comes by shuffle ---- */
+    {
+      float pr = __shfl_up(yi[7], 1), pj = __shfl_up(yq[7], 1);
+      if (lane == 0) { pr = ycr; pj = ycj; }
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        v[r] = discriminate<EX>(pr, pj, yi[r], yq[r]);
+        pr = yi[r]; pj = yq[r];
       }
-      lds_barrier();
-      FMD_STAMP(1)
-      if (dbg_y && !discard) {
-        float2 *o = reinterpret_cast<float2 *>(dbg_y) + slot * M + off + u0;
-        for (int m = tid; m < sm; m += NT) o[m] = s.y[1 + m];
-      }
-
-      discriminate_sub<EX>(u0, sm);
-      const float2 ylast = s.y[sm];
-      lds_barrier();
-      if (tid == 0) s.y[0] = ylast;
-      FMD_STAMP(2)
+      ycr = __shfl(pick8(yi, tm - 1), (tm - 1) >> 3);
+      ycj = __shfl(pick8(yq, tm - 1), (tm - 1) >> 3);
+      f4 *dst = reinterpret_cast<f4 *>(&w.v[HV + m0]);
+      dst[0] = f4{v[0], v[1], v[2], v[3]};
+      dst[1] = f4{v[4], v[5], v[6], v[7]};
       if (dbg_v && !discard) {
-        float *o = dbg_v + slot * M + off + u0;
-        for (int m = tid; m < sm; m += NT) o[m] = s.v[HV + u0 + m];
+        float *o = dbg_v + slot * M + off + m0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if (m0 + r < tm) o[r] = v[r];
       }
-      sm_last = sm;
-      buf ^= 1;
     }
+    FMD_STAMP(2)
 
     /* ---- Q + C: stereo MPX filters ---- */
     if constexpr (MODE == 2) {
-      if (q1 && off == 0 && tm > 1) q1_patch<EX, HALF>(P);
+      if (q1 && off == 0 && tm > 1) q1_patch<EX, HV>(P, tap_mpx, w, lane, pp);
       FMD_STAMP(3)
-      mpx_tile<EX, HALF>(P, tm);
+      mpx_tile<EX, HALF, HV>(P, tap_mpx, w, lane, tm, pp);
       FMD_STAMP(4)
     }
 
@@ -818,40 +793,96 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
     int nq;
     if (P.resample) nq = (int)(((unsigned long long)acc + (unsigned long long)tm * slow) / fast);
     else nq = tm;
-    if (pend + nq * CH > CAPF) {
-      flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr, !discard);
+    if (pend + nq * CH > CAPW) {
+      flush_frames<EX, CH, HV>(P, w, lane, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr,
+                               !discard);
       pcm_off += pend;
       pend = 0;
       FMD_STAMP(8)
     }
-    resample_tile<EX, MODE, HALF>(P, acc, nq, pend);
+    resample_tile<EX, MODE, HALF, HV>(P, tap_mpx, w, lane, acc, nq, pend);
     pend += nq * CH;
     if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)tm * slow) % fast);
-    lds_barrier();
     FMD_STAMP(6)
 
     /* ---- roll the FIR histories to the front of their buffers ---- */
-    roll_history<MODE>(tm);
+    {
+      constexpr int NR = (HV + 63) / 64;
+      float rv[NR];
+      float2 rm[NR];
+#pragma unroll
+      for (int i = 0; i < NR; i++) {             /* all reads first, then all writes (one wave: in order) */
+        const int idx = lane + 64 * i;
+        rv[i] = idx < HV ? w.v[tm + idx] : 0.f;
+        if constexpr (MODE == 2) rm[i] = idx < HV ? w.ms[tm + idx] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const int idx = lane + 64 * i;
+        if (idx < HV) {
+          w.v[idx] = rv[i];
+          if constexpr (MODE == 2) w.ms[idx] = rm[i];
+        }
+      }
+    }
     FMD_STAMP(7)
 
     /* ---- F: end of block -> PCM ---- */
     if (off + tm == M) {
-      lds_barrier();
-      flush_frames<EX, CH>(P, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr, !discard);
-      if (tid == 0 && !discard) lens_all[slot] = pcm_off + pend;
+      flush_frames<EX, CH, HV>(P, w, lane, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr,
+                               !discard);
+      if (lane == 0 && !discard) lens_all[slot] = pcm_off + pend;
+      pend = 0;
       FMD_STAMP(8)
     }
-    pos += tm;
+    tm_last = tm;
+    n_last = n_tile;
+    /* a chunk that ends in the middle of a block hands its pending frames over now */
+    if (g + 1 == t_hi && pend > 0) {
+      flush_frames<EX, CH, HV>(P, w, lane, pend, pcm_blk + pcm_off, mpx_blk ? mpx_blk + pcm_off : nullptr,
+                               !discard);
+      pend = 0;
+    }
   }
 
   /* carried state -> HBM (the chunk that ends the launch) */
-  lds_barrier();
-  if (chunk == K - 1 && n_lo < n_hi) state_out<MODE>(P, state_out_all + stream, buf ^ 1, sm_last, acc);
+  if (chunk == K - 1 && g_first < t_hi) {
+    DevState *st = state_out_all + stream;
+    /* a launch may end in the middle of nothing: blocks are whole, so pend == 0 here */
+    /* lowpass_tb: the last 24 complex samples, rotated, as floats (:366) */
+    if (lane < 48) {
+      const uint8_t *raw = iq_stream + ((size_t)(n_last + tm_last) * 16 - 48);
+      const int j = lane >> 1, comp = lane & 1, p = j & 3;   /* 24 samples: phase = j mod 4 */
+      int sel; float sg;
+      if (P.offset_tuning) { sel = comp; sg = 1.f; }
+      else {
+        sel = comp ? sel_q<true>(p) : sel_i<true>(p);
+        sg = comp ? sgn_q<true>(p) : sgn_i<true>(p);
+      }
+      st->tb[lane] = sg * t0((float)raw[2 * j + sel]);
+    }
+    for (int i = lane; i < size; i += 64) {
+      st->br[i] = w.v[HV - size + i];
+      if constexpr (MODE == 2) {
+        const float2 m = w.ms[HV - size + i];
+        st->bm[i] = m.x;
+        st->bs[i] = m.y;
+      }
+    }
+    if (lane == 0) {
+      st->pre_r = ycr;
+      st->pre_j = ycj;
+      st->pp = (MODE == 2) ? pp : st_in->pp;
+      st->de_l = w.de[0];
+      st->de_r = w.de[1];
+      st->acc = (int32_t)acc;
+    }
+  }
   FMD_STAMP(9)
-  if (dbg_prof && tid == 0) {
-    long long *o = dbg_prof + 16 * (size_t)blockIdx.x;
-    for (int i = 0; i < 10; i++) o[i] = pf[i];
-    o[15] = pf_last - pf_start;
+  if (dbg_prof && lane == 0) {
+    long long *o = dbg_prof + 16 * (size_t)unit;
+    for (int i = 0; i < 10; i++) o[i] = w.prof[i];
+    o[15] = w.prof[11] - w.prof[10];
   }
 #undef FMD_STAMP
 }
@@ -859,7 +890,8 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
 template <bool EX, int MODE, int HALF>
 int launch_one(const fmdk_params *p, int n_streams, const void *iq, void *pcm, void *lens,
                const void *state_in, void *state_out, const fmd_debug_taps *dbg, hipStream_t stream) {
-  hipLaunchKernelGGL((fmd_fused_kernel<EX, MODE, HALF>), dim3(n_streams * p->n_chunks), dim3(NT), 0, stream,
+  const int units = n_streams * p->n_chunks;
+  hipLaunchKernelGGL((fmd_fused_kernel<EX, MODE, HALF>), dim3((units + WPB - 1) / WPB), dim3(NT), 0, stream,
                      *p, static_cast<const uint8_t *>(iq), static_cast<int16_t *>(pcm),
                      static_cast<int32_t *>(lens), static_cast<const DevState *>(state_in),
                      static_cast<DevState *>(state_out),
@@ -897,18 +929,24 @@ extern "C" int fmdk_launch(const fmdk_params *p, int math, int n_streams, const 
   return launch_math<false>(p, n_streams, d_iq, d_pcm, d_lens, d_state_in, d_state_out, dbg, st);
 }
 
-/* FIR memories: 24 IQ + 1 (discriminator) + 2 x (size - 1) rate_in samples; the
- * de-emphasis restart needs warm frames = warm * fast / slow rate_in samples. */
+/* Tiles a replaying chunk must walk before its first real tile.  FIR memories:
+ * 24 IQ + 1 (discriminator) + 2 x (size - 1) rate_in samples; the de-emphasis
+ * restart needs (warm + group) frames = that many x fast / slow rate_in samples.
+ * The last tile of a block may be short, so count tiles against the worst case. */
 extern "C" int fmdk_warm_tiles(const fmdk_params *p) {
   long long need = 8 + 2LL * p->size;
   if (p->deemph) {
-    if (p->warm >= (1 << 20)) return 0;
+    if (p->warm >= (1 << 20)) return 0;          /* non-contracting recurrence: never split */
     need += ((long long)p->warm + DEEMPH_GROUP) * (p->resample ? (p->fast + p->slow - 1) / p->slow : 1);
   }
-  const long long tiles = (need + TM - 1) / TM;
-  if (tiles * TM > (p->block_len >> 4)) return 0;      /* replay must stay inside the previous block */
-  return (int)tiles;
+  const long long M = p->block_len >> 4, tpb = (M + TW - 1) / TW;
+  const long long full = (need + TW - 1) / TW;
+  if (M % TW == 0) return (int)full;
+  if (full + 1 <= tpb) return (int)(full + 1);     /* at most one short tile inside the replay */
+  return (int)(((need + M - 1) / M + 1) * tpb);    /* whole blocks */
 }
+
+extern "C" int fmdk_tile(void) { return TW; }
 
 extern "C" const char *fmdk_kernel_name(const fmdk_params *p, int math) {
   (void)p;
@@ -916,4 +954,4 @@ extern "C" const char *fmdk_kernel_name(const fmdk_params *p, int math) {
   return "fmd_fused_kernel";
 }
 
-extern "C" int fmdk_lds_bytes(void) { return (int)sizeof(Smem); }
+extern "C" int fmdk_lds_bytes(void) { return (int)sizeof(Smem<96>); }
