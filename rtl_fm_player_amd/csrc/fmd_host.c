@@ -185,8 +185,8 @@ static void fill_params(fmd_batch *b) {
   memcpy(k->fm, b->taps.fm, sizeof(k->fm));
   memcpy(k->fp, b->taps.fp, sizeof(k->fp));
   memcpy(k->fs, b->taps.fs, sizeof(k->fs));
-  /* fast path of the /8 low-pass: y = sum_j ts[j] * u[j] + c with the
-   * (u - 127.5)/128 conversion and the j^n rotation signs folded in */
+  /* fast path of the /8 low-pass: y = c + sum_j s[j] (fb[min(j,31-j)] / 128) u[j]
+   * with the (u - 127.5)/128 conversion folded in; s = j^n rotation signs */
   double ci = 0, cq = 0;
   for (int j = 0; j < 32; j++) {
     const float tap = b->taps.fb[j < 16 ? j : 31 - j];
@@ -196,11 +196,10 @@ static void fill_params(fmd_batch *b) {
       si = (p == 0 || p == 3) ? 1.f : -1.f;
       sq = (p == 0 || p == 1) ? 1.f : -1.f;
     }
-    k->ts_i[j] = si * tap / 128.0f;
-    k->ts_q[j] = sq * tap / 128.0f;
     ci += (double)(si * tap);
     cq += (double)(sq * tap);
   }
+  for (int j = 0; j < 16; j++) k->fbs[j] = b->taps.fb[j] / 128.0f;
   k->c_i = (float)(-(127.5 / 128.0) * ci);
   k->c_q = (float)(-(127.5 / 128.0) * cq);
   k->swf = b->taps.swf;

@@ -21,8 +21,7 @@ extern "C" {
  * tap reads with constant indices become scalar loads. */
 typedef struct fmdk_params {
   float fb[16];           /* /8 IQ low-pass, half (reference lp_filter_f32)      */
-  float ts_i[32];         /* fast path: signed taps / 128 applied to the I sum   */
-  float ts_q[32];         /* fast path: signed taps / 128 applied to the Q sum   */
+  float fbs[16];          /* fast path: fb / 128 (exact scaling)                 */
   float c_i, c_q;         /* fast path: constant terms of the folded offset      */
   float fm[128], fp[128], fs[128];
   float swf, cwf, lambda, coef;

@@ -45,6 +45,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <type_traits>
 
 #include "fmd_internal.h"
 
@@ -63,6 +64,7 @@ constexpr float K_PI_2 = 1.5707963f;   /* :41 */
 constexpr float K_PI_4 = 0.78539816f;  /* :42 */
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f8 __attribute__((ext_vector_type(8)));   /* 8 per-lane outputs: an SSA value, never an alloca */
 
 /* history slots in front of each FIR tile: >= size - 1, and >= 92 for the
  * aligned window reads of the 90-tap stereo path */
@@ -73,15 +75,17 @@ struct __attribute__((aligned(16))) WaveMem {
   float v[HV + TW];          /* discriminator output, HV history slots in front   */
   float2 ms[HV + TW];        /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
   float fr[CAPW];            /* resampler outputs waiting for the flush           */
+  uint4 iq[8 * 64 + 4];      /* the tile's IQ, 16-byte word c = 8 * col + row stored at [64 * row + col]
+                                (a lane's 11 window reads are then conflict-free), + 3 halo words */
   float de[4];               /* de-emphasis state: [0..1] current, [2..3] next    */
   float pp[4];               /* scratch for the generic (runtime-size) MPX path   */
+  float head[8];             /* the launch's first three decimator outputs (I,Q)  */
   long long prof[12];        /* per-stage cycle sums (fmd_debug_taps.prof), [11] = last stamp */
 };
 
 template <int HV>
 struct __attribute__((aligned(16))) Smem {
   f4 tap_mpx[128];           /* {fm[k], fp[k], fs[k], 0}, zero beyond size/2 */
-  f4 tap_dec[16];            /* fast /8 low-pass: ts_i[0..31], then ts_q[0..31] */
   WaveMem<HV> w[WPB];
 };
 
@@ -171,26 +175,66 @@ __device__ __forceinline__ int16_t to_s16(float x, float coef) {
   return (int16_t)r;
 }
 
+/* compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- indices stay
+ * constant expressions, so register "arrays" never become private memory */
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+template <int I>
+__device__ __forceinline__ float elem(const f4 &a, const f4 &b, const f4 &c, const f4 &d) {
+  if constexpr (I < 4) return a[I & 3];
+  else if constexpr (I < 8) return b[I & 3];
+  else if constexpr (I < 12) return c[I & 3];
+  else return d[I & 3];
+}
+
 /* element (idx & 7) of an 8-entry register array, idx uniform or per lane */
-__device__ __forceinline__ float pick8(const float (&a)[8], int idx) {
+__device__ __forceinline__ float pick8(const f8 &a, int idx) {
   float r = a[0];
 #pragma unroll
   for (int i = 1; i < 8; i++) r = ((idx & 7) == i) ? a[i] : r;
   return r;
 }
 
-/* ---- tile load ----------------------------------------------------------- */
+/* ---- tile load: global -> LDS, asynchronous ------------------------------- */
 
-/* The 176 bytes (11 x 16 B) that lane's 8 outputs read: rate_in sample n covers
- * IQ bytes [16n, 16n+16) of the stream, output m needs bytes [16m-48, 16m+16).
- * Chunk indices are clamped into the stream (clamped words only ever feed
- * outputs that are masked or patched). */
-__device__ __forceinline__ void load_tile(uint32_t (&d)[44], const uint4 *iq16, int n_first, int n_total) {
+/* rate_in sample n covers IQ bytes [16n, 16n+16) of the stream (one 16-byte
+ * word); output m of the /8 FIR needs words m-3 .. m.  The tile's 512 words are
+ * copied with global_load_lds (no registers, completes in the background): wave
+ * instruction `row` moves word 8 * lane + row of the tile to LDS slot
+ * 64 * row + lane; a ninth, 3-lane instruction fetches the three words in front
+ * of the tile.  Word indices are clamped into the stream (clamped words only
+ * feed outputs that are masked or patched). */
+template <int HV>
+__device__ __forceinline__ void load_tile_async(WaveMem<HV> &w, const uint4 *iq16, int n_tile, int n_total,
+                                                int lane) {
+#pragma unroll
+  for (int row = 0; row < 8; row++) {
+    int c = n_tile + 8 * lane + row;
+    c = c >= n_total ? n_total - 1 : c;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(iq16 + c),
+                                     (__attribute__((address_space(3))) void *)(&w.iq[64 * row]), 16, 0, 0);
+  }
+  if (lane < 3) {
+    int c = n_tile - 3 + lane;
+    c = c < 0 ? 0 : c;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(iq16 + c),
+                                     (__attribute__((address_space(3))) void *)(&w.iq[512]), 16, 0, 0);
+  }
+}
+
+/* The lane's 11 words (outputs 8 * lane .. 8 * lane + 7) from the LDS image. */
+template <int HV>
+__device__ __forceinline__ void read_window(const WaveMem<HV> &w, int lane, uint32_t (&d)[44]) {
 #pragma unroll
   for (int i = 0; i < 11; i++) {
-    int c = n_first - 3 + i;
-    c = c < 0 ? 0 : (c >= n_total ? n_total - 1 : c);
-    const uint4 q = iq16[c];
+    /* word 8 * lane - 3 + i: rows 5..7 of the previous column, then rows 0..7 of column `lane` */
+    const int slot = i < 3 ? (lane ? 64 * (5 + i) + lane - 1 : 512 + i) : 64 * (i - 3) + lane;
+    const uint4 q = w.iq[slot];
     d[4 * i] = q.x; d[4 * i + 1] = q.y; d[4 * i + 2] = q.z; d[4 * i + 3] = q.w;
   }
 }
@@ -211,8 +255,7 @@ template <bool ROT> __device__ __forceinline__ constexpr float sgn_q(int p) {
 /* Eight consecutive outputs from the lane's 88 IQ samples (sample j = bytes
  * 2j, 2j+1 of d[]); output r uses samples 8r .. 8r+31, phase = index mod 4. */
 template <bool EX, bool ROT>
-__device__ __forceinline__ void decimate8(const fmdk_params &P, const f4 *tap_dec, const uint32_t (&d)[44],
-                                          float (&yi)[8], float (&yq)[8]) {
+__device__ __forceinline__ void decimate8(const fmdk_params &P, const uint32_t (&d)[44], f8 &yi, f8 &yq) {
   if constexpr (EX) {
     const int z = opaque_zero();
 #pragma unroll
@@ -237,18 +280,14 @@ __device__ __forceinline__ void decimate8(const fmdk_params &P, const f4 *tap_de
       yq[r] = aq;
     }
   } else {
-    /* offset and 1/128 folded into signed taps: y = c + sum_j ts[j] * u[j], j
-     * ascending.  Sample-outer order: each byte is converted once and feeds the
-     * (up to four) outputs whose window holds it.  The 64 taps sit in registers
-     * for the duration of the stage (16 broadcast LDS reads): as scalar operands
-     * they do not fit the SGPR file next to the kernel's other uniform values. */
-    float tsi[32], tsq[32];
+    /* offset and 1/128 folded into the taps: y = c + sum_j s[j] g[min(j,31-j)] u[j],
+     * j ascending, g = fb / 128 and s the rotation sign (a free operand modifier).
+     * Sample-outer order: each byte is converted once and feeds the (up to four)
+     * outputs whose window holds it; the 16 distinct taps are scalar operands. */
+    const int z = opaque_zero();
+    float g[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const f4 a = tap_dec[i], b = tap_dec[8 + i];
-      tsi[4 * i] = a.x; tsi[4 * i + 1] = a.y; tsi[4 * i + 2] = a.z; tsi[4 * i + 3] = a.w;
-      tsq[4 * i] = b.x; tsq[4 * i + 1] = b.y; tsq[4 * i + 2] = b.z; tsq[4 * i + 3] = b.w;
-    }
+    for (int k = 0; k < 16; k++) g[k] = P.fbs[k + z];
 #pragma unroll
     for (int r = 0; r < 8; r++) { yi[r] = P.c_i; yq[r] = P.c_q; }
 #pragma unroll
@@ -260,8 +299,9 @@ __device__ __forceinline__ void decimate8(const fmdk_params &P, const f4 *tap_de
         const int j = sx - 8 * r;
         if (j >= 0 && j < 32) {
           const int p = j & 3;
-          yi[r] = __builtin_fmaf(tsi[j], ub[sel_i<ROT>(p)], yi[r]);
-          yq[r] = __builtin_fmaf(tsq[j], ub[sel_q<ROT>(p)], yq[r]);
+          const float gk = g[j < 16 ? j : 31 - j];
+          yi[r] = __builtin_fmaf(sgn_i<ROT>(p) * gk, ub[sel_i<ROT>(p)], yi[r]);
+          yq[r] = __builtin_fmaf(sgn_q<ROT>(p) * gk, ub[sel_q<ROT>(p)], yq[r]);
         }
       }
     }
@@ -269,15 +309,15 @@ __device__ __forceinline__ void decimate8(const fmdk_params &P, const f4 *tap_de
 }
 
 /* First three outputs of the launch: their window reaches into the carried
- * float history lowpass_tb (src/rtl_fm_player.c:261-363).  Lanes 0..5 compute
- * the six values (output m = lane / 2, component = lane & 1) and hand them to
- * lane 0, which owns outputs 0..7. */
+ * float history lowpass_tb (src/rtl_fm_player.c:261-363).  Computed once, before
+ * the tile loop, by lanes 0..5 (output m = lane / 2, component = lane & 1) into
+ * head[6]; the first tile's lane 0 then takes them instead of its own. */
 template <bool ROT>
 __device__ __forceinline__ void decimate_head(const fmdk_params &P, const uint8_t *raw, const float *tb,
-                                              int lane, float (&yi)[8], float (&yq)[8]) {
-  float acc = 0.f;
+                                              int lane, float *head) {
   if (lane < 6) {
     const int m = lane >> 1, comp = lane & 1;
+    float acc = 0.f;
     for (int k = 0; k < 16; k++) {
       float pr[2];
       for (int e = 0; e < 2; e++) {
@@ -297,11 +337,7 @@ __device__ __forceinline__ void decimate_head(const fmdk_params &P, const uint8_
       const float prod = (pr[0] + pr[1]) * P.fb[k];
       acc = (k == 0) ? prod : acc + prod;
     }
-  }
-#pragma unroll
-  for (int m = 0; m < 3; m++) {
-    const float a = __shfl(acc, 2 * m), b = __shfl(acc, 2 * m + 1);
-    if (lane == 0) { yi[m] = a; yq[m] = b; }
+    head[lane] = acc;
   }
 }
 
@@ -334,46 +370,26 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx
   if constexpr (HALF == 45) {
     constexpr int R = 8;
     const int m0 = R * lane;
-    float am[R], ap[R], as[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) { am[r] = 0.f; ap[r] = 0.f; as[r] = 0.f; }
+    f8 am = 0.f, ap = 0.f, as = 0.f;
     if (m0 < tm) {
       const f4 *v4 = reinterpret_cast<const f4 *>(w.v) + ((HV + m0 - 92) >> 2);   /* x[i] = v[m0 - 92 + i] */
-      /* chunk c: window x[4c .. 4c+15] and x[88-4c .. 99-4c], taps 4c .. 4c+3.
-       * Two register sets: chunk c+1 is read while chunk c is consumed. */
-      f4 wa[11], wb[11];
-      auto load_chunk = [&](f4 (&x)[11], int c) {
-        x[0] = v4[c]; x[1] = v4[c + 1]; x[2] = v4[c + 2]; x[3] = v4[c + 3];
-        x[4] = v4[22 - c]; x[5] = v4[23 - c]; x[6] = v4[24 - c];
-        x[7] = tap_mpx[4 * c]; x[8] = tap_mpx[4 * c + 1];
-        x[9] = tap_mpx[4 * c + 2]; x[10] = tap_mpx[4 * c + 3];
-      };
-      auto use_chunk = [&](const f4 (&x)[11]) {
-        const float lo[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
-                              x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
-        const float hi[12] = {x[4].x, x[4].y, x[4].z, x[4].w, x[5].x, x[5].y, x[5].z, x[5].w,
-                              x[6].x, x[6].y, x[6].z, x[6].w};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const f4 t = x[7 + kk];
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            const float p = lo[r + kk + 3] + hi[r + 4 - kk];   /* x[r+k+3] + x[r+92-k] */
+      /* chunk c: window x[4c .. 4c+15] and x[88-4c .. 99-4c], taps 4c .. 4c+3 */
+#pragma unroll 1
+      for (int c = 0; c < 12; c++) {          /* rolled: keeps the register footprint at one chunk */
+        const f4 l0 = v4[c], l1 = v4[c + 1], l2 = v4[c + 2], l3 = v4[c + 3];   /* x[4c .. 4c+15]    */
+        const f4 h0 = v4[22 - c], h1 = v4[23 - c], h2 = v4[24 - c];            /* x[88-4c .. 99-4c] */
+        static_for<0, 4>([&](auto kk_) {
+          constexpr int kk = decltype(kk_)::value;
+          const f4 t = tap_mpx[4 * c + kk];
+          static_for<0, R>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            /* x[r+k+3] + x[r+92-k] */
+            const float p = elem<r + kk + 3>(l0, l1, l2, l3) + elem<r + 4 - kk>(h0, h1, h2, h2);
             am[r] = mac<EX>(am[r], p, t.x);
             ap[r] = mac<EX>(ap[r], p, t.y);
             as[r] = mac<EX>(as[r], p, t.z);
-          }
-        }
-      };
-      load_chunk(wa, 0);
-#pragma unroll 1
-      for (int c = 0; c < 12; c += 2) {       /* rolled: the schedule below is the schedule */
-        load_chunk(wb, c + 1);
-        use_chunk(wa);
-        sched_fence();
-        load_chunk(wa, c + 2 < 12 ? c + 2 : 0);   /* the last refill is a harmless re-read of chunk 0 */
-        use_chunk(wb);
-        sched_fence();
+          });
+        });
       }
     }
     const float up = __shfl_up(ap[R - 1], 1);
@@ -381,15 +397,15 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx
     if (m0 < tm) {
       float prev = lane ? up : pp;
       const float swf = P.swf, cwf = P.cwf;
-      float2 o[R];
+      f8 bs;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        o[r] = make_float2(am[r], as[r] * carrier_of<EX>(ap[r], prev, swf, cwf));
+        bs[r] = as[r] * carrier_of<EX>(ap[r], prev, swf, cwf);
         prev = ap[r];
       }
       f4 *dst = reinterpret_cast<f4 *>(&w.ms[HV + m0]);
 #pragma unroll
-      for (int r = 0; r < R; r += 2) dst[r >> 1] = f4{o[r].x, o[r].y, o[r + 1].x, o[r + 1].y};
+      for (int r = 0; r < R; r += 2) dst[r >> 1] = f4{am[r], bs[r], am[r + 1], bs[r + 1]};
     }
     pp = pp_new;
   } else {
@@ -637,10 +653,6 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
   constexpr int CH = (MODE == 2) ? 2 : 1;
   __shared__ Smem<HV> sm;
   for (int i = threadIdx.x; i < 128; i += NT) sm.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
-  if (threadIdx.x < 16) {
-    const float *t = (threadIdx.x < 8 ? P.ts_i : P.ts_q) + 4 * (threadIdx.x & 7);
-    sm.tap_dec[threadIdx.x] = f4{t[0], t[1], t[2], t[3]};
-  }
   __syncthreads();                                /* the only workgroup barrier */
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -699,10 +711,13 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
     if (P.resample) acc = (uint32_t)(((unsigned long long)acc + (unsigned long long)n0 * slow) % fast);
   }
 
-  uint32_t d[44];
   if (g_first < t_hi) {
     const int b0 = g_first / tpb;
-    load_tile(d, iq16, b0 * M + (g_first - b0 * tpb) * TW + 8 * lane, n_total);
+    load_tile_async<HV>(w, iq16, b0 * M + (g_first - b0 * tpb) * TW, n_total, lane);
+  }
+  if (chunk == 0) {
+    if (P.offset_tuning) decimate_head<false>(P, iq_stream, st_in->tb, lane, w.head);
+    else decimate_head<true>(P, iq_stream, st_in->tb, lane, w.head);
   }
   FMD_STAMP(9)
 
@@ -737,17 +752,29 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
     }
 
     /* ---- A: /8 low-pass, 8 outputs per lane, straight from registers ---- */
-    float yi[8], yq[8];
-    if (P.offset_tuning) decimate8<EX, false>(P, sm.tap_dec, d, yi, yq);
-    else decimate8<EX, true>(P, sm.tap_dec, d, yi, yq);
-    if (n_tile == 0 && chunk == 0) {
-      if (P.offset_tuning) decimate_head<false>(P, iq_stream, st_in->tb, lane, yi, yq);
-      else decimate_head<true>(P, iq_stream, st_in->tb, lane, yi, yq);
+    f8 yi, yq;
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the tile's LDS image has landed */
+      uint32_t d[44];
+      read_window<HV>(w, lane, d);
+      if (P.offset_tuning) {
+        /* make the words opaque on this side: otherwise the byte conversions, common
+         * to both sides, are hoisted above the branch and all 176 results are live at once */
+#pragma unroll
+        for (int i = 0; i < 44; i++) asm volatile("" : "+v"(d[i]));
+        decimate8<EX, false>(P, d, yi, yq);
+      } else {
+        decimate8<EX, true>(P, d, yi, yq);
+      }
+    }
+    if (n_tile == 0 && chunk == 0 && lane == 0) {
+#pragma unroll
+      for (int m = 0; m < 3; m++) { yi[m] = w.head[2 * m]; yq[m] = w.head[2 * m + 1]; }
     }
     /* next tile's IQ: in flight while the rest of this tile is computed */
     if (g + 1 < t_hi) {
       const int b2 = (g + 1) / tpb;
-      load_tile(d, iq16, b2 * M + ((g + 1) - b2 * tpb) * TW + m0, n_total);
+      load_tile_async<HV>(w, iq16, b2 * M + ((g + 1) - b2 * tpb) * TW, n_total, lane);
     }
     FMD_STAMP(1)
     if (dbg_y && !discard) {
@@ -761,7 +788,7 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
     {
       float pr = __shfl_up(yi[7], 1), pj = __shfl_up(yq[7], 1);
       if (lane == 0) { pr = ycr; pj = ycj; }
-      float v[8];
+      f8 v;
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         v[r] = discriminate<EX>(pr, pj, yi[r], yq[r]);
