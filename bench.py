@@ -72,6 +72,21 @@ def cpu_baseline(cfg_kw, seconds):
     }
 
 
+def measured_traffic(config):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+    gfx950 correction + WRITE_SIZE, tools/profile_round.sh) when one exists for this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            t = json.load(open(f)).get("hbm_traffic")
+        except (OSError, ValueError):
+            continue
+        if t and t.get("workload") == config:
+            best = (int(t["traffic_bytes_per_launch"]), os.path.basename(f))
+    return best
+
+
 def main():
     args = parse()
     import torch
@@ -197,6 +212,10 @@ def main():
                 "bytes_per_sample": round(algo_bytes / samples_per_step, 4),
             },
         }
+        tr = measured_traffic(out["config"])
+        if tr:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if parity:
             out["parity"] = parity
         if not args.no_cpu and world == 1:
