@@ -166,17 +166,10 @@ def main():
     algo_bytes = S * B * BLOCK_LEN + pcm_bytes                 # u8 IQ in + s16 PCM out, per launch
 
     # ---- gather the per-rank counters over RCCL (no data-path collective) ----
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([samples_per_step * args.steps, int(kernel_ms * 1e6), int(pcm.view(torch.int16).sum().item())],
-                       dtype=torch.int64, device=dev)
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        total_samples = int(sum(int(c[0]) for c in allc))
-    else:
-        total_samples = int(cnt[0])
-    elapsed = float(el.item())
+    from rtl_fm_player_amd.shard import gather_counters
+    rep = gather_counters(dist, dev, elapsed, samples_per_step * args.steps, int(kernel_ms * 1e6),
+                          int(pcm.view(torch.int16).sum().item()))
+    total_samples, elapsed = rep["samples"], rep["elapsed_s"]
 
     if rank == 0:
         value = total_samples / elapsed / 1e6

@@ -1,0 +1,57 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the sharding + counter gather that
+bench.py uses under RCCL (the data path itself has no collective)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rtl_fm_player_amd.shard import gather_counters, shard_streams
+
+
+def test_shard_streams_partition():
+    for total in (1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            parts = [shard_streams(total, world, r) for r in range(world)]
+            assert parts[0][0] == 0
+            assert sum(c for _, c in parts) == total
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f1 == f0 + c0
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard_streams(2048, world, rank)
+    # each rank "processes" its own streams; rank 1 is slower
+    rep = gather_counters(dist, torch.device("cpu"), elapsed_s=1.0 + rank, samples=count * 1000,
+                          kernel_ns=5 + rank, checksum=first)
+    out[rank] = rep
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_counters_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] == out[1]                      # every rank sees the same whole-job view
+    rep = out[0]
+    assert rep["world"] == 2
+    assert rep["elapsed_s"] == 2.0               # MAX over ranks
+    assert rep["samples"] == 2048 * 1000         # whole job
+    assert [r["checksum"] for r in rep["per_rank"]] == [0, 1024]
+    assert [r["kernel_ns"] for r in rep["per_rank"]] == [5, 6]
+
+
+def test_single_process_passthrough():
+    rep = gather_counters(None, torch.device("cpu"), 0.5, 10, 3, 7)
+    assert rep == {"world": 1, "elapsed_s": 0.5, "samples": 10,
+                   "per_rank": [{"samples": 10, "kernel_ns": 3, "checksum": 7}]}
