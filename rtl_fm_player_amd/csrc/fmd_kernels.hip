@@ -70,10 +70,10 @@ typedef float f8 __attribute__((ext_vector_type(8)));   /* 8 per-lane outputs: a
  * aligned window reads of the 90-tap stereo path */
 template <int HALF> constexpr int hist_of() { return HALF == 45 ? 96 : (HALF == 64 ? 128 : 256); }
 
-template <int HV>
+template <int HV, bool STEREO = true>
 struct __attribute__((aligned(16))) WaveMem {
   float v[HV + TW];          /* discriminator output, HV history slots in front   */
-  float2 ms[HV + TW];        /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
+  float2 ms[STEREO ? HV + TW : 2];   /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
   float fr[CAPW];            /* resampler outputs waiting for the flush           */
   uint4 iq[8 * 64 + 4];      /* the tile's IQ, 16-byte word c = 8 * col + row stored at [64 * row + col]
                                 (a lane's 11 window reads are then conflict-free), + 3 halo words */
@@ -83,10 +83,10 @@ struct __attribute__((aligned(16))) WaveMem {
   long long prof[12];        /* per-stage cycle sums (fmd_debug_taps.prof), [11] = last stamp */
 };
 
-template <int HV>
+template <int HV, bool STEREO>
 struct __attribute__((aligned(16))) Smem {
   f4 tap_mpx[128];           /* {fm[k], fp[k], fs[k], 0}, zero beyond size/2 */
-  WaveMem<HV> w[WPB];
+  WaveMem<HV, STEREO> w[WPB];
 };
 
 /* A zero the optimiser cannot see through: indexing the kernarg tap tables with
@@ -200,6 +200,15 @@ __device__ __forceinline__ float pick8(const f8 &a, int idx) {
   return r;
 }
 
+/* ---- discriminator history layout ---------------------------------------------
+ * In the 90-tap stereo kernel the lanes read the v[] window as aligned 16-byte
+ * words at a 32-byte lane stride, a 2-way bank conflict for ds_read_b128 (its
+ * 16-lane groups see only the even 16-byte slots).  Flipping the lowest word-index
+ * bit with bit 4 (word w lives at w ^ ((w >> 4) & 1)) makes every such read
+ * conflict free at no cost in space.  SWZ = false keeps the layout linear. */
+template <bool SWZ> __device__ __forceinline__ int vword(int w4) { return SWZ ? (w4 ^ ((w4 >> 4) & 1)) : w4; }
+template <bool SWZ> __device__ __forceinline__ int vidx(int m) { return SWZ ? (m ^ ((m >> 4) & 4)) : m; }
+
 /* ---- tile load: global -> LDS, asynchronous ------------------------------- */
 
 /* rate_in sample n covers IQ bytes [16n, 16n+16) of the stream (one 16-byte
@@ -209,8 +218,8 @@ __device__ __forceinline__ float pick8(const f8 &a, int idx) {
  * 64 * row + lane; a ninth, 3-lane instruction fetches the three words in front
  * of the tile.  Word indices are clamped into the stream (clamped words only
  * feed outputs that are masked or patched). */
-template <int HV>
-__device__ __forceinline__ void load_tile_async(WaveMem<HV> &w, const uint4 *iq16, int n_tile, int n_total,
+template <int HV, typename WM>
+__device__ __forceinline__ void load_tile_async(WM &w, const uint4 *iq16, int n_tile, int n_total,
                                                 int lane) {
 #pragma unroll
   for (int row = 0; row < 8; row++) {
@@ -228,8 +237,8 @@ __device__ __forceinline__ void load_tile_async(WaveMem<HV> &w, const uint4 *iq1
 }
 
 /* The lane's 11 words (outputs 8 * lane .. 8 * lane + 7) from the LDS image. */
-template <int HV>
-__device__ __forceinline__ void read_window(const WaveMem<HV> &w, int lane, uint32_t (&d)[44]) {
+template <int HV, typename WM>
+__device__ __forceinline__ void read_window(const WM &w, int lane, uint32_t (&d)[44]) {
 #pragma unroll
   for (int i = 0; i < 11; i++) {
     /* word 8 * lane - 3 + i: rows 5..7 of the previous column, then rows 0..7 of column `lane` */
@@ -364,27 +373,33 @@ __device__ __forceinline__ float discriminate(float pr, float pj, float re, floa
  * 12 chunks of 4 (taps 45..47 are zero); a chunk needs 7 aligned 16-byte window
  * reads and 4 tap reads for 8 x 4 x (1 add + 3 FMA).  pp is the pilot output of
  * the sample before the tile (in), of the tile's last sample (out). */
-template <bool EX, int HALF, int HV>
-__device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w, int lane,
+template <bool EX, int HALF, int HV, typename WM>
+__device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx, WM &w, int lane,
                                          int tm, float &pp) {
   if constexpr (HALF == 45) {
     constexpr int R = 8;
     const int m0 = R * lane;
     f8 am = 0.f, ap = 0.f, as = 0.f;
     if (m0 < tm) {
-      const f4 *v4 = reinterpret_cast<const f4 *>(w.v) + ((HV + m0 - 92) >> 2);   /* x[i] = v[m0 - 92 + i] */
-      /* chunk c: window x[4c .. 4c+15] and x[88-4c .. 99-4c], taps 4c .. 4c+3 */
+      const f4 *v4s = reinterpret_cast<const f4 *>(w.v);   /* x[i] = v[m0 - 92 + i], word-swizzled */
+      /* chunk c (8 taps 8c .. 8c+7; 45..47 are zero): window words x[8c .. 8c+19]
+       * and x[84-8c .. 99-8c]: nine 16-byte window reads + eight tap reads for
+       * 8 outputs x 8 taps x (1 add + 3 FMA) */
+      const int wbase = (HV + m0 - 92) >> 2;
 #pragma unroll 1
-      for (int c = 0; c < 12; c++) {          /* rolled: keeps the register footprint at one chunk */
-        const f4 l0 = v4[c], l1 = v4[c + 1], l2 = v4[c + 2], l3 = v4[c + 3];   /* x[4c .. 4c+15]    */
-        const f4 h0 = v4[22 - c], h1 = v4[23 - c], h2 = v4[24 - c];            /* x[88-4c .. 99-4c] */
-        static_for<0, 4>([&](auto kk_) {
+      for (int c = 0; c < 6; c++) {           /* rolled: keeps the register footprint at one chunk */
+        f4 lo[5], hi[4];
+#pragma unroll
+        for (int i = 0; i < 5; i++) lo[i] = v4s[vword<true>(wbase + 2 * c + i)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) hi[i] = v4s[vword<true>(wbase + 21 - 2 * c + i)];
+        static_for<0, 8>([&](auto kk_) {
           constexpr int kk = decltype(kk_)::value;
-          const f4 t = tap_mpx[4 * c + kk];
+          const f4 t = tap_mpx[8 * c + kk];
           static_for<0, R>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            /* x[r+k+3] + x[r+92-k] */
-            const float p = elem<r + kk + 3>(l0, l1, l2, l3) + elem<r + 4 - kk>(h0, h1, h2, h2);
+            constexpr int il = r + kk + 3, ih = r + 8 - kk;    /* x[r+k+3] + x[r+92-k] */
+            const float p = lo[il >> 2][il & 3] + hi[ih >> 2][ih & 3];
             am[r] = mac<EX>(am[r], p, t.x);
             ap[r] = mac<EX>(ap[r], p, t.y);
             as[r] = mac<EX>(as[r], p, t.z);
@@ -474,41 +489,37 @@ __device__ __forceinline__ float fir_mono(const fmdk_params &P, const f4 *tap_mp
 
 /* The two stage-2 FIRs of the stereo path at one instant (:574-591). */
 template <bool EX, int HALF>
-__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_mpx, const float2 *newest,
-                                           float &om, float &os) {
+__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_mpx, const f4 (&tp)[12],
+                                           const float2 *newest, float &om, float &os) {
   om = 0.f; os = 0.f;
   if constexpr (HALF > 0) {
-    constexpr int S = 2 * HALF, G = 8, NG = (HALF + G - 1) / G;     /* groups of 8 taps, last one partial */
+    /* taps come in registers (tp: fm[0..47], loaded once per tile); the 45 pair
+     * reads are issued a group of 9 ahead of the arithmetic that consumes them */
+    constexpr int S = 2 * HALF, G = 9, NG = HALF / G;
+    static_assert(HALF % G == 0, "tap groups");
     const float2 *x0 = newest - (S - 1);
     float2 xa[2 * G], xb[2 * G];
-    float ta[G], tb[G];
-    auto load_group = [&](float2 (&x)[2 * G], float (&t)[G], int g) {
+    auto load_group = [&](float2 (&x)[2 * G], int g) {
 #pragma unroll
       for (int i = 0; i < G; i++) {
-        const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
-        x[2 * i] = x0[kc];
-        x[2 * i + 1] = x0[S - 1 - kc];
-        t[i] = tap_mpx[k].x;
+        x[2 * i] = x0[g * G + i];
+        x[2 * i + 1] = x0[S - 1 - (g * G + i)];
       }
     };
-    auto use_group = [&](const float2 (&x)[2 * G], const float (&t)[G]) {
-#pragma unroll
-      for (int i = 0; i < G; i++) {
-        om = mac<EX>(om, x[2 * i].x + x[2 * i + 1].x, t[i]);
-        os = mac<EX>(os, x[2 * i].y + x[2 * i + 1].y, t[i]);
-      }
-    };
-    static_assert(NG % 2 == 0, "group pairs");
-    load_group(xa, ta, 0);
-#pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-      load_group(xb, tb, g + 1);
-      use_group(xa, ta);
+    load_group(xa, 0);
+    static_for<0, NG>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      float2(&cur)[2 * G] = (g & 1) ? xb : xa;
+      float2(&nxt)[2 * G] = (g & 1) ? xa : xb;
+      if constexpr (g + 1 < NG) load_group(nxt, g + 1);
+      static_for<0, G>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, k = g * G + i;
+        const float t = tp[k >> 2][k & 3];
+        om = mac<EX>(om, cur[2 * i].x + cur[2 * i + 1].x, t);
+        os = mac<EX>(os, cur[2 * i].y + cur[2 * i + 1].y, t);
+      });
       sched_fence();
-      load_group(xa, ta, g + 2 < NG ? g + 2 : 0);
-      use_group(xb, tb);
-      sched_fence();
-    }
+    });
   } else {
     const int size = P.size, half = P.half;
     const float2 *x = newest - (size - 1);
@@ -524,22 +535,24 @@ __device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_m
 /* Block-start quirk (src/rtl_fm_player.c:534-598):
  * when the resampler emits on sample 0 of a block, the right-channel output is
  * stored over discriminator sample 1 before that sample is read. */
-template <bool EX, int HV>
-__device__ __forceinline__ void q1_patch(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w, int lane,
+template <bool EX, int HV, bool SWZ, typename WM>
+__device__ __forceinline__ void q1_patch(const fmdk_params &P, const f4 *tap_mpx, WM &w, int lane,
                                          float pp) {
   float f = 0.f;
   if (lane < 3) {
     const int size = P.size, half = P.half;
-    const float *x = &w.v[HV - (size - 1)];
+    const int x0 = HV - (size - 1);
     const float *tap = reinterpret_cast<const float *>(tap_mpx) + lane;
-    for (int k = 0; k < half; k++) f = mac<EX>(f, x[k] + x[size - 1 - k], tap[4 * k]);
+    for (int k = 0; k < half; k++)
+      f = mac<EX>(f, w.v[vidx<SWZ>(x0 + k)] + w.v[vidx<SWZ>(x0 + size - 1 - k)], tap[4 * k]);
   }
   const float vp = __shfl(f, 1), vs = __shfl(f, 2);
   if (lane == 0) {
     w.ms[HV] = make_float2(f, vs * carrier_of<EX>(vp, pp, P.swf, P.cwf));
     float om, os;
-    fir_stereo<EX, 0>(P, tap_mpx, &w.ms[HV], om, os);
-    w.v[HV + 1] = om - os;
+    const f4 no_tp[12] = {};
+    fir_stereo<EX, 0>(P, tap_mpx, no_tp, &w.ms[HV], om, os);
+    w.v[vidx<SWZ>(HV + 1)] = om - os;
   }
 }
 
@@ -558,17 +571,23 @@ __device__ __forceinline__ int emit_index(uint32_t acc_t, int q, uint32_t slow, 
   return (int)e - 1;
 }
 
-template <bool EX, int MODE, int HALF, int HV>
-__device__ __forceinline__ void resample_tile(const fmdk_params &P, const f4 *tap_mpx, WaveMem<HV> &w,
+template <bool EX, int MODE, int HALF, int HV, typename WM>
+__device__ __forceinline__ void resample_tile(const fmdk_params &P, const f4 *tap_mpx, WM &w,
                                               int lane, uint32_t acc_t, int nq, int pend) {
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
   const float inv_slow = 1.0f / (float)P.slow;
   const bool rs = P.resample != 0;
+  f4 tp[12];                                  /* fm[0..47] for the unrolled stereo FIR */
+  if constexpr (MODE == 2 && HALF > 0) {
+    const float *tf = reinterpret_cast<const float *>(tap_mpx);
+#pragma unroll
+    for (int i = 0; i < 12; i++) tp[i] = f4{tf[16 * i], tf[16 * i + 4], tf[16 * i + 8], tf[16 * i + 12]};
+  }
   for (int q = lane; q < nq; q += 64) {
     const int i = rs ? emit_index(acc_t, q, slow, fast, inv_slow) : q;
     if constexpr (MODE == 2) {
       float om, os;
-      fir_stereo<EX, HALF>(P, tap_mpx, &w.ms[HV + i], om, os);
+      fir_stereo<EX, HALF>(P, tap_mpx, tp, &w.ms[HV + i], om, os);
       *reinterpret_cast<float2 *>(&w.fr[pend + 2 * q]) = make_float2(om + os, om - os);   /* :595-596 */
     } else if constexpr (MODE == 1) {
       w.fr[pend + q] = fir_mono<EX, HALF>(P, tap_mpx, &w.v[HV + i]);
@@ -585,8 +604,8 @@ __device__ __forceinline__ void resample_tile(const fmdk_params &P, const f4 *ta
  * start at the first pending frame restarts the recurrence P.warm frames early
  * from zero (lambda^warm < 1e-12, below fp32 resolution), the others continue
  * from the carried state, so the result equals the sequential evaluation. */
-template <bool EX, int CH, int HV>
-__device__ __forceinline__ void flush_frames(const fmdk_params &P, WaveMem<HV> &w, int lane, int pend,
+template <bool EX, int CH, int HV, typename WM>
+__device__ __forceinline__ void flush_frames(const fmdk_params &P, WM &w, int lane, int pend,
                                              int16_t *pcm_out, float *mpx_dbg, bool store) {
   const int frames = pend / CH;
   const float coef = P.coef;
@@ -651,7 +670,8 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
                                                       float *dbg_v, float *dbg_mpx, long long *dbg_prof) {
   constexpr int HV = hist_of<HALF>();
   constexpr int CH = (MODE == 2) ? 2 : 1;
-  __shared__ Smem<HV> sm;
+  constexpr bool SWZ = (MODE == 2 && HALF == 45);   /* word-swizzled discriminator history */
+  __shared__ Smem<HV, MODE == 2> sm;
   for (int i = threadIdx.x; i < 128; i += NT) sm.tap_mpx[i] = f4{P.fm[i], P.fp[i], P.fs[i], 0.f};
   __syncthreads();                                /* the only workgroup barrier */
 
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
   const int unit = blockIdx.x * WPB + wave;
   if (unit >= P.n_streams * K) return;
   const int stream = unit / K, chunk = unit - stream * K;
-  WaveMem<HV> &w = sm.w[wave];
+  WaveMem<HV, MODE == 2> &w = sm.w[wave];
   const f4 *tap_mpx = sm.tap_mpx;
 
   /* optional per-stage cycle accounting (fmd_debug_taps.prof): lane 0 keeps the
@@ -694,7 +714,7 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
   /* carried state (chunk 0) or zero state (replaying chunks) */
   const bool carried = (chunk == 0);
   for (int i = lane; i < size; i += 64) {
-    w.v[HV - size + i] = carried ? st_in->br[i] : 0.f;
+    w.v[vidx<SWZ>(HV - size + i)] = carried ? st_in->br[i] : 0.f;
     if constexpr (MODE == 2)
       w.ms[HV - size + i] = carried ? make_float2(st_in->bm[i], st_in->bs[i]) : make_float2(0.f, 0.f);
   }
@@ -796,9 +816,9 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
       }
       ycr = __shfl(pick8(yi, tm - 1), (tm - 1) >> 3);
       ycj = __shfl(pick8(yq, tm - 1), (tm - 1) >> 3);
-      f4 *dst = reinterpret_cast<f4 *>(&w.v[HV + m0]);
-      dst[0] = f4{v[0], v[1], v[2], v[3]};
-      dst[1] = f4{v[4], v[5], v[6], v[7]};
+      f4 *dst = reinterpret_cast<f4 *>(w.v);
+      dst[vword<SWZ>((HV + m0) >> 2)] = f4{v[0], v[1], v[2], v[3]};
+      dst[vword<SWZ>(((HV + m0) >> 2) + 1)] = f4{v[4], v[5], v[6], v[7]};
       if (dbg_v && !discard) {
         float *o = dbg_v + slot * M + off + m0;
 #pragma unroll
@@ -810,7 +830,7 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
 
     /* ---- Q + C: stereo MPX filters ---- */
     if constexpr (MODE == 2) {
-      if (q1 && off == 0 && tm > 1) q1_patch<EX, HV>(P, tap_mpx, w, lane, pp);
+      if (q1 && off == 0 && tm > 1) q1_patch<EX, HV, SWZ>(P, tap_mpx, w, lane, pp);
       FMD_STAMP(3)
       mpx_tile<EX, HALF, HV>(P, tap_mpx, w, lane, tm, pp);
       FMD_STAMP(4)
@@ -840,14 +860,14 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
 #pragma unroll
       for (int i = 0; i < NR; i++) {             /* all reads first, then all writes (one wave: in order) */
         const int idx = lane + 64 * i;
-        rv[i] = idx < HV ? w.v[tm + idx] : 0.f;
+        rv[i] = idx < HV ? w.v[vidx<SWZ>(tm + idx)] : 0.f;
         if constexpr (MODE == 2) rm[i] = idx < HV ? w.ms[tm + idx] : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < NR; i++) {
         const int idx = lane + 64 * i;
         if (idx < HV) {
-          w.v[idx] = rv[i];
+          w.v[vidx<SWZ>(idx)] = rv[i];
           if constexpr (MODE == 2) w.ms[idx] = rm[i];
         }
       }
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(NT, 2) void fmd_fused_kernel(const fmdk_params P, c
       st->tb[lane] = sg * t0((float)raw[2 * j + sel]);
     }
     for (int i = lane; i < size; i += 64) {
-      st->br[i] = w.v[HV - size + i];
+      st->br[i] = w.v[vidx<SWZ>(HV - size + i)];
       if constexpr (MODE == 2) {
         const float2 m = w.ms[HV - size + i];
         st->bm[i] = m.x;
@@ -981,4 +1001,4 @@ extern "C" const char *fmdk_kernel_name(const fmdk_params *p, int math) {
   return "fmd_fused_kernel";
 }
 
-extern "C" int fmdk_lds_bytes(void) { return (int)sizeof(Smem<96>); }
+extern "C" int fmdk_lds_bytes(void) { return (int)sizeof(Smem<96, true>); }
