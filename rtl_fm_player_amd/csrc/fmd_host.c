@@ -222,6 +222,7 @@ static void fill_params(fmd_batch *b) {
     else if (lam >= 1.0) warm = 1 << 30;   /* not contracting: never restart */
     else warm = (int)ceil(log(1e-12) / log(lam));
     if (warm < 16) warm = 16;
+    if (warm < (1 << 29)) warm = (warm + 15) & ~15;   /* the kernel restarts in whole 16-frame blocks */
   }
   k->warm = warm;
   k->block_len = c->block_len;

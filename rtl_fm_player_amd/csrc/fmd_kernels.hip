@@ -74,7 +74,8 @@ template <int HV, bool STEREO = true>
 struct __attribute__((aligned(16))) WaveMem {
   float v[HV + TW];          /* discriminator output, HV history slots in front   */
   float2 ms[STEREO ? HV + TW : 2];   /* stereo: {L+R low-pass, (L-R band-pass) x carrier} */
-  float fr[CAPW];            /* resampler outputs waiting for the flush           */
+  float fr[CAPW + CAPW / 32];/* resampler outputs waiting for the flush; one pad float per 32 (fidx):
+                                flush lanes stride 16 frames x channels = 32 floats apart     */
   uint4 iq[8 * 64 + 4];      /* the tile's IQ, 16-byte word c = 8 * col + row stored at [64 * row + col]
                                 (a lane's 11 window reads are then conflict-free), + 3 halo words */
   float de[4];               /* de-emphasis state: [0..1] current, [2..3] next    */
@@ -123,13 +124,20 @@ __device__ __forceinline__ float ubyte(uint32_t w, int i) {
 /* (u - 127.5) / 128: exact in fp32, one fused op (reference table [0]) */
 __device__ __forceinline__ float t0(float u) { return __builtin_fmaf(u, 0.0078125f, -0.99609375f); }
 
+/* a / b: IEEE division in the exact kernels, v_rcp_f32 (1 ulp) and a multiply in the fast ones */
+template <bool EX>
+__device__ __forceinline__ float fdiv(float a, float b) {
+  if constexpr (EX) return a / b;
+  else return a * __builtin_amdgcn_rcpf(b);
+}
+
 /* src/rtl_fm_player.c:606-667 through the magnitude ratio (see oracle/fm_oracle.c) */
 template <bool EX>
 __device__ __forceinline__ float poly_atan2(float y, float x) {
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
   const bool xmaj = ax >= ay;
   const float num = xmaj ? ay : ax, den = xmaj ? ax : ay;
-  const float a = num / den;                                /* IEEE divide */
+  const float a = fdiv<EX>(num, den);
   float r0;
   if constexpr (EX) {
     r0 = a * (K_PI_4 - (a - 1.f) * (0.2447f + 0.0663f * a));
@@ -151,9 +159,13 @@ __device__ __forceinline__ float poly_atan2(float y, float x) {
 }
 
 /* src/rtl_fm_player.c:472-481 */
+template <bool EX>
 __device__ __forceinline__ float carrier38(float x, float y) {
-  const float z = y / x;
-  const float c = (z + z) / (1.f + (z * z));
+  const float z = fdiv<EX>(y, x);
+  float den;
+  if constexpr (EX) den = 1.f + (z * z);
+  else den = __builtin_fmaf(z, z, 1.f);
+  const float c = fdiv<EX>(z + z, den);
   return (x == 0.f) ? 0.f : c;
 }
 
@@ -163,7 +175,7 @@ __device__ __forceinline__ float carrier_of(float vp, float vq, float swf, float
   float y;
   if constexpr (EX) y = vp * cwf - vq;
   else y = __builtin_fmaf(vp, cwf, -vq);
-  return carrier38(x, y);
+  return carrier38<EX>(x, y);
 }
 
 /* src/rtl_fm_player.c:711-735 */
@@ -199,6 +211,9 @@ __device__ __forceinline__ float pick8(const f8 &a, int idx) {
   for (int i = 1; i < 8; i++) r = ((idx & 7) == i) ? a[i] : r;
   return r;
 }
+
+/* index into the padded pending-frame buffer */
+__device__ __forceinline__ int fidx(int i) { return i + (i >> 5); }
 
 /* ---- discriminator history layout ---------------------------------------------
  * In the 90-tap stereo kernel the lanes read the v[] window as aligned 16-byte
@@ -448,37 +463,34 @@ __device__ __forceinline__ void mpx_tile(const fmdk_params &P, const f4 *tap_mpx
 
 /* Symmetric fm FIR over the `2*HALF` floats ending at newest (mono, :511-529). */
 template <bool EX, int HALF>
-__device__ __forceinline__ float fir_mono(const fmdk_params &P, const f4 *tap_mpx, const float *newest) {
+__device__ __forceinline__ float fir_mono(const fmdk_params &P, const f4 *tap_mpx, const f4 (&tp)[16],
+                                          const float *newest) {
   float acc = 0.f;
   if constexpr (HALF > 0) {
-    constexpr int S = 2 * HALF, G = 16, NG = (HALF + G - 1) / G;
+    /* taps come in registers (tp: fm[0..63]); the pair reads run a group of 16 ahead */
+    constexpr int S = 2 * HALF, G = 16, NG = HALF / G;
+    static_assert(HALF % G == 0, "tap groups");
     const float *x0 = newest - (S - 1);
-    float xa[2 * G], xb[2 * G], ta[G], tb[G];
-    /* taps beyond HALF are zero in tap_mpx; window indices are clamped into the window */
-    auto load_group = [&](float (&x)[2 * G], float (&t)[G], int g) {
+    float xa[2 * G], xb[2 * G];
+    auto load_group = [&](float (&x)[2 * G], int g) {
 #pragma unroll
       for (int i = 0; i < G; i++) {
-        const int k = g * G + i, kc = k < HALF ? k : HALF - 1;
-        x[2 * i] = x0[kc];
-        x[2 * i + 1] = x0[S - 1 - kc];
-        t[i] = tap_mpx[k].x;
+        x[2 * i] = x0[g * G + i];
+        x[2 * i + 1] = x0[S - 1 - (g * G + i)];
       }
     };
-    auto use_group = [&](const float (&x)[2 * G], const float (&t)[G]) {
-#pragma unroll
-      for (int i = 0; i < G; i++) acc = mac<EX>(acc, x[2 * i] + x[2 * i + 1], t[i]);
-    };
-    static_assert(NG % 2 == 0, "group pairs");
-    load_group(xa, ta, 0);
-#pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-      load_group(xb, tb, g + 1);
-      use_group(xa, ta);
+    load_group(xa, 0);
+    static_for<0, NG>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      float(&cur)[2 * G] = (g & 1) ? xb : xa;
+      float(&nxt)[2 * G] = (g & 1) ? xa : xb;
+      if constexpr (g + 1 < NG) load_group(nxt, g + 1);
+      static_for<0, G>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, k = g * G + i;
+        acc = mac<EX>(acc, cur[2 * i] + cur[2 * i + 1], tp[k >> 2][k & 3]);
+      });
       sched_fence();
-      load_group(xa, ta, g + 2 < NG ? g + 2 : 0);
-      use_group(xb, tb);
-      sched_fence();
-    }
+    });
   } else {
     const int size = P.size, half = P.half;
     const float *x = newest - (size - 1);
@@ -489,7 +501,7 @@ __device__ __forceinline__ float fir_mono(const fmdk_params &P, const f4 *tap_mp
 
 /* The two stage-2 FIRs of the stereo path at one instant (:574-591). */
 template <bool EX, int HALF>
-__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_mpx, const f4 (&tp)[12],
+__device__ __forceinline__ void fir_stereo(const fmdk_params &P, const f4 *tap_mpx, const f4 (&tp)[16],
                                            const float2 *newest, float &om, float &os) {
   om = 0.f; os = 0.f;
   if constexpr (HALF > 0) {
@@ -550,7 +562,7 @@ __device__ __forceinline__ void q1_patch(const fmdk_params &P, const f4 *tap_mpx
   if (lane == 0) {
     w.ms[HV] = make_float2(f, vs * carrier_of<EX>(vp, pp, P.swf, P.cwf));
     float om, os;
-    const f4 no_tp[12] = {};
+    const f4 no_tp[16] = {};
     fir_stereo<EX, 0>(P, tap_mpx, no_tp, &w.ms[HV], om, os);
     w.v[vidx<SWZ>(HV + 1)] = om - os;
   }
@@ -577,22 +589,23 @@ __device__ __forceinline__ void resample_tile(const fmdk_params &P, const f4 *ta
   const uint32_t slow = (uint32_t)P.slow, fast = (uint32_t)P.fast;
   const float inv_slow = 1.0f / (float)P.slow;
   const bool rs = P.resample != 0;
-  f4 tp[12];                                  /* fm[0..47] for the unrolled stereo FIR */
-  if constexpr (MODE == 2 && HALF > 0) {
+  f4 tp[16];                                  /* fm[0..63] for the unrolled FIRs */
+  if constexpr (MODE != 0 && HALF > 0) {
     const float *tf = reinterpret_cast<const float *>(tap_mpx);
 #pragma unroll
-    for (int i = 0; i < 12; i++) tp[i] = f4{tf[16 * i], tf[16 * i + 4], tf[16 * i + 8], tf[16 * i + 12]};
+    for (int i = 0; i < 16; i++) tp[i] = f4{tf[16 * i], tf[16 * i + 4], tf[16 * i + 8], tf[16 * i + 12]};
   }
   for (int q = lane; q < nq; q += 64) {
     const int i = rs ? emit_index(acc_t, q, slow, fast, inv_slow) : q;
     if constexpr (MODE == 2) {
       float om, os;
       fir_stereo<EX, HALF>(P, tap_mpx, tp, &w.ms[HV + i], om, os);
-      *reinterpret_cast<float2 *>(&w.fr[pend + 2 * q]) = make_float2(om + os, om - os);   /* :595-596 */
+      w.fr[fidx(pend + 2 * q)] = om + os;          /* :595 */
+      w.fr[fidx(pend + 2 * q + 1)] = om - os;      /* :596 */
     } else if constexpr (MODE == 1) {
-      w.fr[pend + q] = fir_mono<EX, HALF>(P, tap_mpx, &w.v[HV + i]);
+      w.fr[fidx(pend + q)] = fir_mono<EX, HALF>(P, tap_mpx, tp, &w.v[HV + i]);
     } else {
-      w.fr[pend + q] = w.v[HV + i];
+      w.fr[fidx(pend + q)] = w.v[HV + i];
     }
   }
 }
@@ -610,7 +623,7 @@ __device__ __forceinline__ void flush_frames(const fmdk_params &P, WM &w, int la
   const int frames = pend / CH;
   const float coef = P.coef;
   if (mpx_dbg) {
-    for (int i = lane; i < pend; i += 64) mpx_dbg[i] = w.fr[i];
+    for (int i = lane; i < pend; i += 64) mpx_dbg[i] = w.fr[fidx(i)];
   }
   if (P.deemph) {
     const int groups = (frames + DEEMPH_GROUP - 1) / DEEMPH_GROUP;
@@ -621,30 +634,53 @@ __device__ __forceinline__ void flush_frames(const fmdk_params &P, WM &w, int la
     if (lane < groups * CH) {
       const int g = lane / CH, c = lane % CH;
       const int f_out = g * DEEMPH_GROUP;
-      int f = f_out - warm;
-      float y = 0.f;
-      if (f <= 0) { f = 0; y = w.de[c]; }
       const int f_end = min(f_out + DEEMPH_GROUP, frames);
-#pragma unroll 4
-      for (; f < f_out; f++) {             /* warm-up, nothing stored */
-        const float x = w.fr[f * CH + c];
-        const float t = y - x;
-        if constexpr (EX) y = x + lam * t;
-        else y = __builtin_fmaf(lam, t, x);
+      int fb = f_out - warm;                  /* warm is a multiple of 16 (host), so is f_out */
+      float y = 0.f;
+      if (fb <= 0) { fb = 0; y = w.de[c]; }
+      /* blocks of 16 steps: the 16 inputs do not depend on the recurrence, so they
+       * are read together (one LDS latency per block instead of one per step) */
+      for (; fb < f_out; fb += 16) {          /* warm-up blocks: whole, nothing stored */
+        f8 xa, xb;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          xa[j] = w.fr[fidx((fb + j) * CH + c)];
+          xb[j] = w.fr[fidx((fb + 8 + j) * CH + c)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float x = j < 8 ? xa[j & 7] : xb[j & 7];
+          const float t = y - x;
+          if constexpr (EX) y = x + lam * t;
+          else y = __builtin_fmaf(lam, t, x);
+        }
       }
-      for (; f < f_end; f++) {
-        const float x = w.fr[f * CH + c];
-        const float t = y - x;
-        if constexpr (EX) y = x + lam * t;
-        else y = __builtin_fmaf(lam, t, x);
-        if (store) pcm_out[f * CH + c] = to_s16(y, coef);
+      {                                        /* the lane's own 16 frames (the last group may be short) */
+        f8 xa, xb;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          xa[j] = w.fr[fidx(min(f_out + j, frames - 1) * CH + c)];
+          xb[j] = w.fr[fidx(min(f_out + 8 + j, frames - 1) * CH + c)];
+        }
+        int16_t *o = pcm_out + f_out * CH + c;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float x = j < 8 ? xa[j & 7] : xb[j & 7];
+          const float t = y - x;
+          float yn;
+          if constexpr (EX) yn = x + lam * t;
+          else yn = __builtin_fmaf(lam, t, x);
+          const bool live = f_out + j < f_end;
+          y = live ? yn : y;
+          if (store && live) o[j * CH] = to_s16(yn, coef);
+        }
       }
       ylast = y;
       have_last = (f_end == frames);
     }
     if (have_last) w.de[lane % CH] = ylast;      /* all lanes have read de[] above (same wave) */
   } else if (store) {
-    for (int i = lane; i < pend; i += 64) pcm_out[i] = to_s16(w.fr[i], coef);
+    for (int i = lane; i < pend; i += 64) pcm_out[i] = to_s16(w.fr[fidx(i)], coef);
   }
 }
 
