@@ -266,6 +266,20 @@ void fmd_ingest_mute(fmd_ingest *g, int n_bytes);
  * fmd_batch_run_host, for max_blocks blocks. */
 int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens);
 
+/* ------------------------------------------------------------------------
+ * 4. WAV output in the reference's format (InitWaveOut / CloseWaveOut,
+ *    src/rtl_fm_player.c:1259-1328; headers include/rtl_fm_player.h:216-253)
+ * ------------------------------------------------------------------------
+ * 260-byte header (44-byte PCM header, 16 bit / 48000 Hz / mode == 2 ? stereo :
+ * mono, then 216 zero bytes); close patches the sizes at offsets 4 and 40.
+ * path "-" writes to stdout (sizes then stay at the reference's placeholders). */
+#define FMD_WAV_HEADER_BYTES 260
+typedef struct fmd_wav fmd_wav;
+int fmd_wav_header(int mode, unsigned char out[FMD_WAV_HEADER_BYTES]);
+int fmd_wav_open(fmd_wav **out, const char *path, int mode);
+int fmd_wav_write(fmd_wav *w, const int16_t *pcm, size_t n_values);
+int fmd_wav_close(fmd_wav *w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,7 @@ _EXPORTS = [
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
     "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_batch_pump",
+    "fmd_wav_header", "fmd_wav_open", "fmd_wav_write", "fmd_wav_close",
 ]
 
 INGEST_CB = C.CFUNCTYPE(None, C.POINTER(C.c_ubyte), C.c_uint32, C.c_void_p)

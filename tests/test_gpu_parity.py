@@ -215,3 +215,80 @@ def test_drop_in_full_demod(R, lcg40):
     ring = [d.lpr.br[(d.lpr.pos + i) % 90] for i in range(90)]
     assert ring == list(st.br)[:90]
     L.deinit_lp_real_f32(C.byref(d))
+
+
+def test_ingest_callback_and_pump(R):
+    """rtlsdr_read_async-shaped ingest: odd-sized callback buffers -> pinned ring -> batch."""
+    from oracle import OracleStream, lcg_bytes
+    L = R.lib()
+    ns, nb = 2, 3
+    cfg = R.wbfm_config(math=R.MATH_EXACT, **CONFIGS["stereo_300k"])
+    b = R.BatchDemod(cfg, ns)
+    iqs = [lcg_bytes(nb * BL + 12345, 777 + s)[0] for s in range(ns)]       # a partial block is left over
+    rings = []
+    for s in range(ns):
+        h = C.c_void_p()
+        assert L.fmd_ingest_create(C.byref(h), b._h, s, 0) == 0
+        rings.append(h)
+    for s in range(ns):
+        pos = 0
+        while pos < iqs[s].size:                                            # 100000-byte "USB transfers"
+            n = min(100000, iqs[s].size - pos)
+            chunk = np.ascontiguousarray(iqs[s][pos:pos + n])
+            L.fmd_ingest_callback(chunk.ctypes.data, n, rings[s])
+            pos += n
+        assert L.fmd_ingest_buffered(rings[s]) == iqs[s].size
+        assert L.fmd_ingest_dropped(rings[s]) == 0
+    pcm = np.zeros((ns, 8, b.pcm_stride), dtype=np.int16)
+    lens = np.zeros((ns, 8), dtype=np.int32)
+    got = L.fmd_batch_pump(b._h, 8, pcm.ctypes.data, lens.ctypes.data)
+    assert got == nb                                                        # only whole blocks
+    pcm = pcm.reshape(-1)[: ns * nb * b.pcm_stride].reshape(ns, nb, b.pcm_stride)
+    lens = lens.reshape(-1)[: ns * nb].reshape(ns, nb)
+    for s in range(ns):
+        want, wl = OracleStream(**CONFIGS["stereo_300k"]).run(iqs[s][: nb * BL], BL)
+        assert np.array_equal(lens[s], wl)
+        assert np.array_equal(np.concatenate([pcm[s, k, :lens[s, k]] for k in range(nb)]), want)
+        assert L.fmd_ingest_buffered(rings[s]) == 12345
+        L.fmd_ingest_destroy(rings[s])
+
+
+def test_ingest_overflow_keeps_newest(R):
+    L = R.lib()
+    cfg = R.wbfm_config(math=R.MATH_EXACT, block_len=4096, **CONFIGS["mono_300k"])
+    b = R.BatchDemod(cfg, 1)
+    h = C.c_void_p()
+    assert L.fmd_ingest_create(C.byref(h), b._h, 0, 8192) == 0
+    data = (np.arange(3 * 8192) % 251).astype(np.uint8)
+    for k in range(6):
+        chunk = np.ascontiguousarray(data[k * 4096:(k + 1) * 4096])
+        L.fmd_ingest_callback(chunk.ctypes.data, 4096, h)
+    assert L.fmd_ingest_buffered(h) == 8192 and L.fmd_ingest_dropped(h) == 4 * 4096
+    L.fmd_ingest_destroy(h)
+
+
+@pytest.mark.parametrize("wav", [False, True])
+def test_replay_driver(R, tmp_path, wav):
+    """fmd_replay = the reference's demod thread for recorded IQ: whole blocks only, PCM/WAV out."""
+    import os
+    import subprocess
+    from oracle import OracleStream, lcg_bytes
+    exe = os.path.join(os.path.dirname(R.library_path()), "fmd_replay")
+    nb = 5
+    files, iqs = [], []
+    for s in range(2):
+        iq = lcg_bytes(nb * BL + 999, 4242 + s)[0]
+        p = tmp_path / ("in%d.u8" % s)
+        iq.tofile(p)
+        files.append(str(p)); iqs.append(iq)
+    prefix = str(tmp_path / "out")
+    cmd = [exe, "-s", "300000", "-e", "-n", "2", "-o", prefix] + (["-w"] if wav else []) + files
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for s in range(2):
+        want, _ = OracleStream(**CONFIGS["stereo_300k"]).run(iqs[s][: nb * BL], BL)
+        raw = open(prefix + "%d.%s" % (s, "wav" if wav else "pcm"), "rb").read()
+        if wav:
+            assert raw[:4] == b"RIFF" and int.from_bytes(raw[40:44], "little") == len(raw) - 44
+            raw = raw[260:]
+        assert np.array_equal(np.frombuffer(raw, dtype=np.int16), want)
