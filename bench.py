@@ -40,11 +40,41 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg_kw, seconds):
     """The oracle (a bit-exact CPU port of the reference path) on this host's cores:
     one independent stream per thread, bounded sample of the same workload."""
     from oracle import OracleStream, lcg_bytes
-    n_thr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_thr = usable_cores()
     nb = 8
     iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
     streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
@@ -67,8 +97,9 @@ def cpu_baseline(cfg_kw, seconds):
         "unit": "Msamples/s",
         "cores": n_thr,
         "kind": "port",
-        "sample": "%d threads x independent streams, %d-block runs of LCG u8 IQ for %.0f s "
-                  "(oracle/fm_oracle.c, -O3 -ffp-contract=off)" % (n_thr, nb, dt),
+        "sample": "%d threads (affinity capped by the cgroup CPU quota) x independent streams on %s, %d-block "
+                  "runs of LCG u8 IQ for %.0f s (oracle/fm_oracle.c, -O3 -ffp-contract=off)"
+                  % (n_thr, cpu_model(), nb, dt),
     }
 
 

@@ -217,7 +217,9 @@ int fmd_batch_n_streams(const fmd_batch *b);
  *   d_pcm  s16 [n_streams][n_blocks][pcm_stride]
  *   d_lens i32 [n_streams][n_blocks]          (result_len of each block)
  * hip_stream: a hipStream_t passed as void* (NULL = the batch's own stream).
- * Asynchronous; state advances by n_blocks blocks per stream. */
+ * d_iq must be 16-byte aligned.  Asynchronous; state advances by n_blocks blocks
+ * per stream.  Internally each stream's tiles are cut into time chunks so that
+ * every CU holds 8 workers; results do not depend on that. */
 int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
                          void *d_lens, void *hip_stream);
 int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libfmdemod_mi355x.so")
+_LIB = os.environ.get("FMD_LIB_PATH") or os.path.join(_HERE, "libfmdemod_mi355x.so")   # override: kernel experiments
 
 MATH_EXACT = 0
 MATH_FAST = 1

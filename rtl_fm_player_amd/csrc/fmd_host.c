@@ -12,6 +12,7 @@
 #include <pthread.h>
 #include <stdarg.h>
 #include <stddef.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -303,6 +304,9 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   if (!b || !d_iq || !d_pcm || !d_lens) return fail(FMD_E_ARG, "NULL argument");
   if (n_blocks < 0) return fail(FMD_E_ARG, "n_blocks < 0");
   if (n_blocks == 0) return FMD_OK;
+  if (((uintptr_t)d_iq & 15) != 0) return fail(FMD_E_ARG, "d_iq must be 16-byte aligned");
+  if ((long long)(b->cfg.block_len >> 4) * n_blocks >= (1LL << 31))
+    return fail(FMD_E_ARG, "n_blocks too large: block_len / 16 * n_blocks must stay below 2^31");
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->stream;
   fmdk_params kp = b->kp;
