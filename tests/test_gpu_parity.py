@@ -292,3 +292,95 @@ def test_replay_driver(R, tmp_path, wav):
             assert raw[:4] == b"RIFF" and int.from_bytes(raw[40:44], "little") == len(raw) - 44
             raw = raw[260:]
         assert np.array_equal(np.frombuffer(raw, dtype=np.int16), want)
+
+
+def test_full_size_batch_properties(R):
+    """BASELINE.json configs[2] at full size (256 streams x 16 blocks, device resident),
+    through properties that do not need 256 oracle runs:
+      * every stream fed the same IQ produces the same PCM (streams are independent and the
+        time-chunk replay is deterministic), and that PCM equals the oracle's (bit-exact);
+      * distinct inputs in odd streams do not disturb the even streams."""
+    import torch
+    from oracle import OracleStream, lcg_bytes
+    S, B = 256, 16
+    dev = torch.device("cuda:0")
+    base = lcg_bytes(B * BL, 2024)[0]
+    other = lcg_bytes(B * BL, 99)[0]
+    iq = torch.empty((S, B * BL), dtype=torch.uint8, device=dev)
+    iq[0::2] = torch.from_numpy(base).to(dev)
+    iq[1::2] = torch.from_numpy(other).to(dev)
+    want, wl = OracleStream(**CONFIGS["stereo_300k"]).run(base, BL)
+    want_o, wl_o = OracleStream(**CONFIGS["stereo_300k"]).run(other, BL)
+    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+        b = R.BatchDemod(R.wbfm_config(math=math, **CONFIGS["stereo_300k"]), S)
+        pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+        lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        b.run_device(iq, B, pcm, lens)
+        b.sync()
+        assert bool((lens[0::2] == torch.from_numpy(wl).to(dev)).all())
+        assert bool((lens[1::2] == torch.from_numpy(wl_o).to(dev)).all())
+        assert bool((pcm[0::2] == pcm[0]).all()) and bool((pcm[1::2] == pcm[1]).all())
+        for s, (w, l) in ((0, (want, wl)), (1, (want_o, wl_o)), (254, (want, wl)), (255, (want_o, wl_o))):
+            p = pcm[s].cpu().numpy()
+            got = np.concatenate([p[k, :l[k]] for k in range(B)])
+            assert np.abs(got.astype(np.int32) - w.astype(np.int32)).max() <= tol
+        b.close()
+
+
+def test_chunking_does_not_change_results(R, lcg40, monkeypatch):
+    """The same launch with and without time chunks (FMD_NO_TIME_SPLIT) and with a different
+    worker target gives identical PCM and identical carried state."""
+    nb = 16
+    outs, states = [], []
+    for env in ({"FMD_NO_TIME_SPLIT": "1"}, {"FMD_WORKERS_PER_CU": "3"}, {}):
+        for k in ("FMD_NO_TIME_SPLIT", "FMD_WORKERS_PER_CU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, lens, b = gpu_run(R, CONFIGS["stereo_300k"], lcg40[: nb * BL], nb, R.MATH_EXACT)
+        outs.append(got[0])
+        st = b.get_state(0)
+        states.append((st.acc, st.pre_r, st.pre_j, st.pp, st.deemph_l, st.deemph_r, list(st.br)[:90], list(st.bs)[:90]))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert states[0] == states[1] == states[2]
+
+
+def test_misaligned_iq_pointer_is_rejected(R):
+    import torch
+    cfg = R.wbfm_config(math=R.MATH_FAST, **CONFIGS["stereo_300k"])
+    b = R.BatchDemod(cfg, 1)
+    dev = torch.device("cuda:0")
+    buf = torch.zeros(BL + 64, dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(b.pcm_stride, dtype=torch.int16, device=dev)
+    lens = torch.zeros(1, dtype=torch.int32, device=dev)
+    with pytest.raises(R.FmdError, match="16-byte aligned"):
+        b.run_device(buf.data_ptr() + 4, 1, pcm, lens)
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode):
+    """Noise is the worst case for a non-bit-exact discriminator: phase steps land arbitrarily
+    close to the +-pi branch cut, where a last-bit difference flips the output by 2 pi.  The fast
+    kernels redo such samples in exact arithmetic; seed 99 holds a known crossing (block 4)."""
+    import torch
+    from oracle import OracleStream, lcg_bytes
+    S, B = 24, 8
+    kw = dict(rate_in=300000, rate_out2=48000, mode=mode)
+    dev = torch.device("cuda:0")
+    seeds = [99] + list(range(5000, 5000 + S - 1))
+    host = [lcg_bytes(B * BL, sd)[0] for sd in seeds]
+    iq = torch.stack([torch.from_numpy(h) for h in host]).to(dev)
+    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **kw), S)
+    pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+    lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    b.run_device(iq, B, pcm, lens)
+    b.sync()
+    for i in range(S):
+        want, wl = OracleStream(**kw).run(host[i], BL)
+        p, l = pcm[i].cpu().numpy(), lens[i].cpu().numpy()
+        assert np.array_equal(l, wl)
+        got = np.concatenate([p[k, :l[k]] for k in range(B)])
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1, "seed %d: |diff| %d at %d" % (seeds[i], d.max(), int(d.argmax()))

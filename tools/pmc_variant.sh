@@ -1,0 +1,16 @@
+#!/bin/bash
+# Usage (GPU box): tools/pmc_variant.sh <lib.so> "<counters>"  -> per-launch counter means for the fused kernel
+LIB=$1; CNT="$2"
+OUT=/tmp/pmcv_$$
+cd /tmp && export TMPDIR=/tmp
+FMD_LIB_PATH=$LIB rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-check > /dev/null 2>&1 || true
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "fmd_" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print({k: round(sum(v) / len(v) / 1e6, 2) for k, v in acc.items()}, "(millions per launch)")
+PY
+rm -rf $OUT
