@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
     ap.add_argument("--math", choices=["fast", "exact"], default="fast")
-    ap.add_argument("--mode", choices=["stereo", "mono"], default="stereo")
+    ap.add_argument("--mode", choices=["stereo", "mono", "nfm"], default="stereo",
+                    help="stereo/mono: 2.4 Msps WBFM (rate_in 300k -> 48k); nfm: 200 ksps (25k -> 12.5k mono)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -137,7 +138,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     stereo = args.mode == "stereo"
-    cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
+    if args.mode == "nfm":
+        cfg_kw = dict(rate_in=25000, rate_out2=12500, mode=1)          # BASELINE.json configs[4]
+    else:
+        cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
     math = R.MATH_FAST if args.math == "fast" else R.MATH_EXACT
     cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math, **cfg_kw)
     S, B = args.streams, args.blocks
@@ -219,8 +223,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d concurrent 2.4 Msps %s WBFM streams per GPU x %d blocks of %d B u8 IQ "
-                            "(rate_in 300k -> 48k PCM), IQ resident in HBM" % (S, args.mode, B, BLOCK_LEN),
+                "workload": ("%d concurrent 2.4 Msps %s WBFM streams per GPU x %d blocks of %d B u8 IQ "
+                             "(rate_in 300k -> 48k PCM), IQ resident in HBM" % (S, args.mode, B, BLOCK_LEN))
+                if args.mode != "nfm" else
+                ("%d concurrent 200 ksps narrow-FM mono streams per GPU x %d blocks of %d B u8 IQ "
+                 "(rate_in 25k -> 12.5k PCM), IQ resident in HBM" % (S, B, BLOCK_LEN)),
                 "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
             },
