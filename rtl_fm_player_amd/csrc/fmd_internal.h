@@ -15,7 +15,7 @@ extern "C" {
 
 #define FMDK_TILE 512         /* rate_in samples per tile: 64 lanes x 8 outputs           */
 #define FMDK_WAVES 4          /* workers (wavefronts) per workgroup                       */
-#define FMDK_FRAME_CAP 1024   /* pending resampler outputs (floats) per worker before a flush */
+#define FMDK_FRAME_CAP 512    /* pending resampler outputs (floats) per worker before a flush */
 
 /* Uniform launch parameters, passed by value in the kernarg segment so that
  * tap reads with constant indices become scalar loads. */
@@ -47,6 +47,7 @@ int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq,
  * de-emphasis recurrence has converged (0: the launch must not be split). */
 int fmdk_warm_tiles(const fmdk_params *p);
 int fmdk_tile(void);
+int fmdk_workers_per_cu(int math);
 /* Mangled-free kernel name as rocprofv3 prints it (prefix match). */
 const char *fmdk_kernel_name(const fmdk_params *p, int math);
 /* Static LDS bytes of the fused kernel (for DESIGN.md / diagnostics). */

@@ -3,7 +3,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/rtl_fm_player_amd/csrc
-F=fast; case "${1:-ILb0}" in ILb1*) F=exact; EXTRA="$EXTRA -fno-slp-vectorize";; esac; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I$ROOT/include -I$SRC $EXTRA -S --cuda-device-only -o /tmp/k.s $SRC/fmd_kernels_$F.hip 2>/dev/null
+F=fast; EXTRA="$EXTRA -fno-slp-vectorize"; case "${1:-ILb0}" in ILb1*) F=exact;; esac; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I$ROOT/include -I$SRC $EXTRA -S --cuda-device-only -o /tmp/k.s $SRC/fmd_kernels_$F.hip 2>/dev/null
 K=${1:-ILb0ELi2ELi45}
 START=$(grep -n "^_ZN.*fmd_fused_kernel${K}[A-Za-z0-9_]*: " /tmp/k.s | head -1 | cut -d: -f1)
 tail -n +$START /tmp/k.s | awk '{print} /s_endpgm/ {exit}' > /tmp/k_sel.s
