@@ -305,8 +305,8 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   if (n_blocks < 0) return fail(FMD_E_ARG, "n_blocks < 0");
   if (n_blocks == 0) return FMD_OK;
   if (((uintptr_t)d_iq & 15) != 0) return fail(FMD_E_ARG, "d_iq must be 16-byte aligned");
-  if ((long long)(b->cfg.block_len >> 4) * n_blocks >= (1LL << 31))
-    return fail(FMD_E_ARG, "n_blocks too large: block_len / 16 * n_blocks must stay below 2^31");
+  if ((long long)b->cfg.block_len * n_blocks >= (1LL << 32))   /* one raw buffer (32-bit size) per stream */
+    return fail(FMD_E_ARG, "n_blocks too large: block_len * n_blocks must stay below 2^32 bytes per stream");
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->stream;
   fmdk_params kp = b->kp;

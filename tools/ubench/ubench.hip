@@ -58,6 +58,98 @@ __global__ void k_cvt(float *out, unsigned w) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the MPX inner pattern: one pair-sum feeds three FMAs whose tap is a scalar (SGPR) operand
+template <int NACC>
+__global__ void k_mpx(float *out, float t0, float t1, float t2, float t3, float t4, float t5) {
+  float am[NACC], ap[NACC], as[NACC], x[NACC + 4];
+  for (int i = 0; i < NACC; i++) { am[i] = threadIdx.x + i; ap[i] = i; as[i] = -i; }
+  for (int i = 0; i < NACC + 4; i++) x[i] = threadIdx.x * 0.001f + i;
+  for (int it = 0; it < ITERS / 2; it++) {
+#pragma unroll
+    for (int i = 0; i < NACC; i++) {
+      float p = x[i] + x[i + 3];
+      am[i] = __builtin_fmaf(p, t0, am[i]); ap[i] = __builtin_fmaf(p, t1, ap[i]); as[i] = __builtin_fmaf(p, t2, as[i]);
+      float q = x[i + 1] + x[i + 4];
+      am[i] = __builtin_fmaf(q, t3, am[i]); ap[i] = __builtin_fmaf(q, t4, ap[i]); as[i] = __builtin_fmaf(q, t5, as[i]);
+    }
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+  }
+  float s = 0; for (int i = 0; i < NACC; i++) s += am[i] + ap[i] + as[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// same arithmetic with the iteration loop unrolled UNR times: straight-line code of UNR x 64
+// instructions, to see what instruction fetch costs when the body is long
+template <int UNR>
+__global__ void k_mpx_long(float *out, float t0, float t1, float t2, float t3, float t4, float t5) {
+  constexpr int NACC = 8;
+  float am[NACC], ap[NACC], as[NACC], x[NACC + 4];
+  for (int i = 0; i < NACC; i++) { am[i] = threadIdx.x + i; ap[i] = i; as[i] = -i; }
+  for (int i = 0; i < NACC + 4; i++) x[i] = threadIdx.x * 0.001f + i;
+  for (int it = 0; it < ITERS / 2 / UNR; it++) {
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) {
+        float p = x[i] + x[i + 3];
+        am[i] = __builtin_fmaf(p, t0, am[i]); ap[i] = __builtin_fmaf(p, t1, ap[i]); as[i] = __builtin_fmaf(p, t2, as[i]);
+        float q = x[i + 1] + x[i + 4];
+        am[i] = __builtin_fmaf(q, t3, am[i]); ap[i] = __builtin_fmaf(q, t4, ap[i]); as[i] = __builtin_fmaf(q, t5, as[i]);
+      }
+      asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    }
+  }
+  float s = 0; for (int i = 0; i < NACC; i++) s += am[i] + ap[i] + as[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// VOP3 (8-byte) encodings of the same arithmetic with the iteration loop unrolled UNR times: straight-line code of UNR x 64
+// instructions, to see what instruction fetch costs when the body is long
+template <int UNR>
+__global__ void k_mpx_long_vop3(float *out, float t0, float t1, float t2, float t3, float t4, float t5) {
+  constexpr int NACC = 8;
+  float am[NACC], ap[NACC], as[NACC], x[NACC + 4];
+  for (int i = 0; i < NACC; i++) { am[i] = threadIdx.x + i; ap[i] = i; as[i] = -i; }
+  for (int i = 0; i < NACC + 4; i++) x[i] = threadIdx.x * 0.001f + i;
+  for (int it = 0; it < ITERS / 2 / UNR; it++) {
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) {
+        float p = x[i] + x[i + 3];
+        am[i] = __builtin_fmaf(__builtin_fabsf(p), t0, am[i]); ap[i] = __builtin_fmaf(__builtin_fabsf(p), t1, ap[i]); as[i] = __builtin_fmaf(__builtin_fabsf(p), t2, as[i]);
+        float q = x[i + 1] + x[i + 4];
+        am[i] = __builtin_fmaf(__builtin_fabsf(q), t3, am[i]); ap[i] = __builtin_fmaf(__builtin_fabsf(q), t4, ap[i]); as[i] = __builtin_fmaf(__builtin_fabsf(q), t5, as[i]);
+      }
+      asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    }
+  }
+  float s = 0; for (int i = 0; i < NACC; i++) s += am[i] + ap[i] + as[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// plain VOP2 ops with two VGPR sources
+__global__ void k_add2(float *out, float a) {
+  float acc[16], x[16];
+  for (int i = 0; i < 16; i++) { acc[i] = threadIdx.x + i; x[i] = i * a; }
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = acc[i] + x[(i + 5) & 15];
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+  }
+  float s = 0; for (int i = 0; i < 16; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// fma with three VGPR sources
+__global__ void k_fma3(float *out, float a) {
+  float acc[16], x[16], y[16];
+  for (int i = 0; i < 16; i++) { acc[i] = threadIdx.x + i; x[i] = i * a; y[i] = 1.f + i * a; }
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __builtin_fmaf(x[(i + 5) & 15], y[(i + 3) & 15], acc[i]);
+    asm volatile("" : "+v"(x[0]), "+v"(y[1]));
+  }
+  float s = 0; for (int i = 0; i < 16; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __shared__ f4 lds[4096];
 // LDS reads: mode 0 = b128 distinct contiguous, 1 = b128 broadcast (same address), 2 = b64 contiguous,
 //            3 = b32 contiguous, 4 = b96-like broadcast (use 3 of 4), 5 = b64 broadcast
@@ -109,6 +201,21 @@ int main() {
     float t4 = time_kernel([&] { hipLaunchKernelGGL(k_cvt, dim3(cus), dim3(threads), 0, 0, out, 12345u); });
     printf("waves/SIMD %d: fma %.3f ms = %.1f Tlane-FMA/s | pk_fma %.3f ms = %.1f Tlane-FMA/s | add+fma %.3f ms = %.1f Tlane-op/s | cvt+add %.3f ms = %.1f Tlane-op/s\n",
            wpsimd, t1, lane_ops / t1 / 1e9, t2, lane_ops / t2 / 1e9, t3, lane_ops / t3 / 1e9, t4, lane_ops / t4 / 1e9);
+  }
+  for (int wpsimd : {1, 2, 3, 4}) {
+    int threads = 64 * 4 * wpsimd;
+    double ops8 = (double)cus * threads * (ITERS / 2) * 8 * 8, ops16 = (double)cus * threads * ITERS * 16;
+    float m8 = time_kernel([&] { hipLaunchKernelGGL(k_mpx<8>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float a2 = time_kernel([&] { hipLaunchKernelGGL(k_add2, dim3(cus), dim3(threads), 0, 0, out, 1.0001f); });
+    float f3 = time_kernel([&] { hipLaunchKernelGGL(k_fma3, dim3(cus), dim3(threads), 0, 0, out, 1.0001f); });
+    float l4 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long<4>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float l32 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long<32>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float l128 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long<128>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float v4 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long_vop3<4>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float v128 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long_vop3<128>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    printf("waves/SIMD %d: 8-byte encodings x4 %.1f x128 %.1f T lane-instr/s\n", wpsimd, ops8 / v4 / 1e9, ops8 / v128 / 1e9);
+    printf("waves/SIMD %d: mpx pattern %.3f ms = %.1f T lane-instr/s | add vgpr,vgpr %.1f | fma vgpr,vgpr,vgpr %.1f | straight-line x4 %.1f x32 %.1f x128 %.1f\n", wpsimd, m8,
+           ops8 / m8 / 1e9, ops16 / a2 / 1e9, ops16 / f3 / 1e9, ops8 / l4 / 1e9, ops8 / l32 / 1e9, ops8 / l128 / 1e9);
   }
   for (int wpsimd : {1, 2, 4}) {
     int threads = 64 * 4 * wpsimd;
