@@ -206,6 +206,10 @@ static void fill_params(fmd_batch *b) {
   k->swf = b->taps.swf;
   k->cwf = b->taps.cwf;
   k->lambda = c->deemph_lambda;
+  {
+    float lp = c->deemph_lambda;
+    for (int j = 0; j < 16; j++) { k->lam_pow[j] = lp; lp *= c->deemph_lambda; }
+  }
   k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */
   k->size = c->size;
   k->half = c->size >> 1;

@@ -25,6 +25,7 @@ typedef struct fmdk_params {
   float c_i, c_q;         /* fast path: constant terms of the folded offset      */
   float fm[128], fp[128], fs[128];
   float swf, cwf, lambda, coef;
+  float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
   int32_t size, half, mode;
   int32_t slow, fast;     /* rate_out2, rate_out                                 */
   int32_t resample;       /* rate_out2 > 0                                       */
