@@ -230,6 +230,12 @@ static void fill_params(fmd_batch *b) {
     if (warm < (1 << 29)) warm = (warm + 15) & ~15;   /* the kernel restarts in whole 16-frame blocks */
   }
   k->warm = warm;
+  k->warm_fast = 0;
+  if (k->deemph) {
+    const double lam = fabs((double)c->deemph_lambda);
+    k->warm_fast = (lam > 0.0 && lam < 1.0) ? (int)ceil(log(1e-9) / log(lam)) : warm;
+    if (k->warm_fast < 1) k->warm_fast = 1;
+  }
   k->block_len = c->block_len;
   k->pcm_stride = b->pcm_stride;
 }
@@ -319,7 +325,7 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
    * workers (wavefronts) per CU; each chunk > 0 replays warm_tiles tiles first
    * (see the kernel), so keep chunks at least 8x longer than the replay. */
   kp.n_streams = b->n_streams;
-  kp.warm_tiles = fmdk_warm_tiles(&kp);
+  kp.warm_tiles = fmdk_warm_tiles(&kp, b->cfg.math);
   kp.n_chunks = 1;
   if (kp.warm_tiles > 0 && !getenv("FMD_NO_TIME_SPLIT")) {
     const char *e_w = getenv("FMD_WORKERS_PER_CU");

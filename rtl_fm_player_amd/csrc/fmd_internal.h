@@ -36,6 +36,7 @@ typedef struct fmdk_params {
   int32_t pcm_stride;     /* int16 per (stream, block)                           */
   int32_t n_streams;
   int32_t n_chunks;       /* time chunks (workers) per stream                    */
+  int32_t warm_fast;      /* frames after which a zero de-emphasis state is right to 1e-9 */
   int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
 } fmdk_params;
 
@@ -46,7 +47,7 @@ int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq,
                 void *hip_stream);
 /* Tiles a time chunk must replay so that every FIR history is exact and the
  * de-emphasis recurrence has converged (0: the launch must not be split). */
-int fmdk_warm_tiles(const fmdk_params *p);
+int fmdk_warm_tiles(const fmdk_params *p, int math);
 int fmdk_tile(void);
 int fmdk_workers_per_cu(int math);
 /* Mangled-free kernel name as rocprofv3 prints it (prefix match). */
