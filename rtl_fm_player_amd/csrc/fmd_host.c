@@ -184,6 +184,19 @@ static void fill_params(fmd_batch *b) {
   memset(k, 0, sizeof(*k));
   memcpy(k->fb, b->taps.fb, sizeof(k->fb));
   memcpy(k->fm, b->taps.fm, sizeof(k->fm));
+  memset(k->hm, 0, sizeof(k->hm));
+  if (c->size == 90) {
+    /* h = fm * fm (179 taps, symmetric); accumulated in double from the float taps */
+    const int S = c->size;
+    for (int m = 0; m < S; m++) {
+      double acc = 0.0;
+      for (int j = 0; j <= m; j++) {
+        const int a = j < S - 1 - j ? j : S - 1 - j, r = m - j, bq = r < S - 1 - r ? r : S - 1 - r;
+        acc += (double)b->taps.fm[a] * (double)b->taps.fm[bq];
+      }
+      k->hm[m] = (float)(m == S - 1 ? 0.5 * acc : acc);
+    }
+  }
   memcpy(k->fp, b->taps.fp, sizeof(k->fp));
   memcpy(k->fs, b->taps.fs, sizeof(k->fs));
   /* fast path of the /8 low-pass: y = c + sum_j s[j] (fb[min(j,31-j)] / 128) u[j]
