@@ -80,6 +80,12 @@ def cpu_baseline(cfg_kw, seconds):
     iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
     streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
     streams[0].run(iqs[0], BLOCK_LEN)                      # page in / warm up
+    t1 = time.perf_counter()                               # 1 thread x 1 stream as well
+    n1 = 0
+    while time.perf_counter() - t1 < min(2.0, seconds / 4):
+        streams[0].run(iqs[0], BLOCK_LEN)
+        n1 += nb * BLOCK_LEN // 2
+    single = n1 / (time.perf_counter() - t1) / 1e6
     done = [0] * n_thr
     stop = time.perf_counter() + seconds
 
@@ -98,10 +104,31 @@ def cpu_baseline(cfg_kw, seconds):
         "unit": "Msamples/s",
         "cores": n_thr,
         "kind": "port",
+        "single_thread": round(single, 2),
         "sample": "%d threads (affinity capped by the cgroup CPU quota) x independent streams on %s, %d-block "
                   "runs of LCG u8 IQ for %.0f s (oracle/fm_oracle.c, -O3 -ffp-contract=off)"
                   % (n_thr, cpu_model(), nb, dt),
     }
+
+
+def copy_bandwidth(torch, dev, stream, nbytes=1 << 30):
+    """Device-to-device copy of 1 GiB (read + write counted), the practical HBM ceiling on this part."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    best = 0.0
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            dst.copy_(src)
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            dst.copy_(src)
+            b.record(stream)
+            b.synchronize()
+            best = max(best, 2.0 * nbytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del src, dst
+    return best
 
 
 def measured_traffic(config):
@@ -207,6 +234,7 @@ def main():
     total_samples, elapsed = rep["samples"], rep["elapsed_s"]
 
     if rank == 0:
+        copy_gbs = copy_bandwidth(torch, dev, stream) if S * B * BLOCK_LEN <= (1 << 31) else 0.0
         value = total_samples / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -238,6 +266,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
+                "copy_kernel_gbs": round(copy_gbs, 1),           # measured d2d copy on this device (read + write)
+                "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None,
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_sample": round(algo_bytes / samples_per_step, 4),
