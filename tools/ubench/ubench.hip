@@ -125,6 +125,31 @@ __global__ void k_mpx_long_vop3(float *out, float t0, float t1, float t2, float 
   float s = 0; for (int i = 0; i < NACC; i++) s += am[i] + ap[i] + as[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// v_dot4_i32_i8 with a scalar tap operand: is the integer dot product full rate?
+__global__ void k_dot4(int *out, int t0, int t1, int t2) {
+  int acc[16], x[8];
+  for (int i = 0; i < 16; i++) acc[i] = threadIdx.x + i;
+  for (int i = 0; i < 8; i++) x[i] = threadIdx.x * 0x01010101 + i * 0x00030507;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __builtin_amdgcn_sdot4(x[i & 7], (i % 3 == 0) ? t0 : ((i % 3 == 1) ? t1 : t2), acc[i], false);
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+  }
+  int s = 0; for (int i = 0; i < 16; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_perm(int *out, int sel) {
+  int acc[16], x[8];
+  for (int i = 0; i < 16; i++) acc[i] = threadIdx.x + i;
+  for (int i = 0; i < 8; i++) x[i] = threadIdx.x * 0x01010101 + i * 0x00030507;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __builtin_amdgcn_perm(acc[i], x[i & 7], sel);
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+  }
+  int s = 0; for (int i = 0; i < 16; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // plain VOP2 ops with two VGPR sources
 __global__ void k_add2(float *out, float a) {
   float acc[16], x[16];
@@ -213,6 +238,9 @@ int main() {
     float l128 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long<128>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
     float v4 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long_vop3<4>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
     float v128 = time_kernel([&] { hipLaunchKernelGGL(k_mpx_long_vop3<128>, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    float d4 = time_kernel([&] { hipLaunchKernelGGL(k_dot4, dim3(cus), dim3(threads), 0, 0, (int *)out, 0x01020304, 0x7f80fe01, 0x10203040); });
+    float pm = time_kernel([&] { hipLaunchKernelGGL(k_perm, dim3(cus), dim3(threads), 0, 0, (int *)out, 0x07020500); });
+    printf("waves/SIMD %d: v_dot4_i32_i8 %.1f T lane-instr/s | v_perm_b32 %.1f\n", wpsimd, ops16 / d4 / 1e9, ops16 / pm / 1e9);
     printf("waves/SIMD %d: 8-byte encodings x4 %.1f x128 %.1f T lane-instr/s\n", wpsimd, ops8 / v4 / 1e9, ops8 / v128 / 1e9);
     printf("waves/SIMD %d: mpx pattern %.3f ms = %.1f T lane-instr/s | add vgpr,vgpr %.1f | fma vgpr,vgpr,vgpr %.1f | straight-line x4 %.1f x32 %.1f x128 %.1f\n", wpsimd, m8,
            ops8 / m8 / 1e9, ops16 / a2 / 1e9, ops16 / f3 / 1e9, ops8 / l4 / 1e9, ops8 / l32 / 1e9, ops8 / l128 / 1e9);
