@@ -267,6 +267,14 @@ void fmd_ingest_mute(fmd_ingest *g, int n_bytes);
  * number of blocks processed per stream (>= 0) or an error.  pcm/lens as in
  * fmd_batch_run_host, for max_blocks blocks. */
 int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens);
+/* Pipelined form of the same: _begin stages what is buffered (ring -> pinned memory),
+ * queues H2D, kernel and D2H and returns the job's block count at once (0: nothing
+ * buffered); _end waits for the oldest job begun and hands out its PCM and lengths.
+ * Two jobs may be in flight, so staging and H2D of one overlap the kernel of the other
+ * (the demod thread's copy / demodulate alternation, src/rtl_fm_player.c:871-889,
+ * without the serialisation). */
+int fmd_batch_pump_begin(fmd_batch *b, int max_blocks);
+int fmd_batch_pump_end(fmd_batch *b, int16_t *pcm, int32_t *lens);
 
 /* ------------------------------------------------------------------------
  * 4. WAV output in the reference's format (InitWaveOut / CloseWaveOut,

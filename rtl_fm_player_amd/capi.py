@@ -98,6 +98,7 @@ _EXPORTS = [
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
     "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_batch_pump",
+    "fmd_batch_pump_begin", "fmd_batch_pump_end",
     "fmd_wav_header", "fmd_wav_open", "fmd_wav_write", "fmd_wav_close",
 ]
 
@@ -155,6 +156,8 @@ def lib():
     L.fmd_ingest_mute.argtypes = [vp, C.c_int]
     L.fmd_ingest_mute.restype = None
     L.fmd_batch_pump.argtypes = [vp, C.c_int, vp, vp]
+    L.fmd_batch_pump_begin.argtypes = [vp, C.c_int]
+    L.fmd_batch_pump_end.argtypes = [vp, vp, vp]
     for name in ("init_lp_real_f32", "deinit_lp_real_f32", "demod_init", "rotate_90_u8_f32", "u8_f32",
                  "full_demod", "fmd_demod_release"):
         getattr(L, name).argtypes = [C.POINTER(DemodState)]

@@ -165,8 +165,16 @@ struct fmd_batch {
   size_t cap_blocks;
   /* ingest */
   struct fmd_ingest **ingest;  /* [n_streams], NULL when unbound */
-  uint8_t *pump_iq;            /* pinned host staging for fmd_batch_pump */
-  size_t pump_cap;
+  /* fmd_batch_pump_begin/_end: two jobs in flight, each with its own pinned and device buffers */
+  struct pump_slot {
+    uint8_t *h_iq; int16_t *h_pcm; int32_t *h_lens;   /* pinned */
+    void *d_iq, *d_pcm, *d_lens;
+    size_t cap_blocks;
+    int n_blocks;                                      /* > 0: job in flight */
+    hipEvent_t h2d_done, done;
+  } pump[2];
+  int pump_head, pump_tail;    /* next slot to begin / oldest slot not yet ended */
+  hipStream_t copy_stream;     /* H2D of job k+1 runs beside the kernel of job k */
 };
 
 static int max_result_len(const fmd_config *c) {
@@ -184,19 +192,6 @@ static void fill_params(fmd_batch *b) {
   memset(k, 0, sizeof(*k));
   memcpy(k->fb, b->taps.fb, sizeof(k->fb));
   memcpy(k->fm, b->taps.fm, sizeof(k->fm));
-  memset(k->hm, 0, sizeof(k->hm));
-  if (c->size == 90) {
-    /* h = fm * fm (179 taps, symmetric); accumulated in double from the float taps */
-    const int S = c->size;
-    for (int m = 0; m < S; m++) {
-      double acc = 0.0;
-      for (int j = 0; j <= m; j++) {
-        const int a = j < S - 1 - j ? j : S - 1 - j, r = m - j, bq = r < S - 1 - r ? r : S - 1 - r;
-        acc += (double)b->taps.fm[a] * (double)b->taps.fm[bq];
-      }
-      k->hm[m] = (float)(m == S - 1 ? 0.5 * acc : acc);
-    }
-  }
   memcpy(k->fp, b->taps.fp, sizeof(k->fp));
   memcpy(k->fs, b->taps.fs, sizeof(k->fs));
   /* fast path of the /8 low-pass: y = c + sum_j s[j] (fb[min(j,31-j)] / 128) u[j]
@@ -308,7 +303,18 @@ void fmd_batch_destroy(fmd_batch *b) {
   if (b->d_iq) hipFree(b->d_iq);
   if (b->d_pcm) hipFree(b->d_pcm);
   if (b->d_lens) hipFree(b->d_lens);
-  if (b->pump_iq) hipHostFree(b->pump_iq);
+  for (int i = 0; i < 2; i++) {
+    struct pump_slot *p = &b->pump[i];
+    if (p->h_iq) hipHostFree(p->h_iq);
+    if (p->h_pcm) hipHostFree(p->h_pcm);
+    if (p->h_lens) hipHostFree(p->h_lens);
+    if (p->d_iq) hipFree(p->d_iq);
+    if (p->d_pcm) hipFree(p->d_pcm);
+    if (p->d_lens) hipFree(p->d_lens);
+    if (p->h2d_done) hipEventDestroy(p->h2d_done);
+    if (p->done) hipEventDestroy(p->done);
+  }
+  if (b->copy_stream) hipStreamDestroy(b->copy_stream);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->stream) hipStreamDestroy(b->stream);
@@ -713,8 +719,39 @@ void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx) {
 uint32_t fmd_ingest_buffered(const fmd_ingest *g) { return g ? g->size : 0; }
 uint64_t fmd_ingest_dropped(const fmd_ingest *g) { return g ? g->dropped : 0; }
 
-int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens) {
-  if (!b || !pcm || !lens || max_blocks <= 0) return fail(FMD_E_ARG, "bad argument");
+static int pump_slot_reserve(fmd_batch *b, struct pump_slot *p, int nb) {
+  if (!p->done) {
+    HIP_TRY(hipEventCreateWithFlags(&p->h2d_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+  }
+  if ((size_t)nb <= p->cap_blocks) return FMD_OK;
+  if (p->h_iq) hipHostFree(p->h_iq);
+  if (p->h_pcm) hipHostFree(p->h_pcm);
+  if (p->h_lens) hipHostFree(p->h_lens);
+  if (p->d_iq) hipFree(p->d_iq);
+  if (p->d_pcm) hipFree(p->d_pcm);
+  if (p->d_lens) hipFree(p->d_lens);
+  p->h_iq = NULL; p->h_pcm = NULL; p->h_lens = NULL; p->d_iq = p->d_pcm = p->d_lens = NULL;
+  p->cap_blocks = 0;
+  const size_t slots = (size_t)b->n_streams * (size_t)nb;
+  HIP_TRY(hipHostMalloc((void **)&p->h_iq, slots * (size_t)b->cfg.block_len, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&p->h_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&p->h_lens, slots * sizeof(int32_t), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(&p->d_iq, slots * (size_t)b->cfg.block_len));
+  HIP_TRY(hipMalloc(&p->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t)));
+  HIP_TRY(hipMalloc(&p->d_lens, slots * sizeof(int32_t)));
+  p->cap_blocks = (size_t)nb;
+  return FMD_OK;
+}
+
+/* Start one job: whole blocks that every bound stream has buffered (at most max_blocks)
+ * are moved from the rings into pinned memory, then H2D (copy stream), kernel and D2H
+ * (batch stream) are queued and the call returns.  Up to two jobs may be in flight, so
+ * the ring -> pinned copy and the H2D of job k+1 overlap the kernel of job k. */
+int fmd_batch_pump_begin(fmd_batch *b, int max_blocks) {
+  if (!b || max_blocks <= 0) return fail(FMD_E_ARG, "bad argument");
+  struct pump_slot *p = &b->pump[b->pump_head];
+  if (p->n_blocks > 0) return fail(FMD_E_STATE, "two jobs already in flight: call fmd_batch_pump_end first");
   const uint32_t bl = (uint32_t)b->cfg.block_len;
   int nb = max_blocks;
   for (int s = 0; s < b->n_streams; s++) {
@@ -727,17 +764,12 @@ int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens) {
   }
   if (nb == 0) return 0;
   HIP_TRY(hipSetDevice(b->device));
-  const size_t need = (size_t)b->n_streams * (size_t)nb * bl;
-  if (need > b->pump_cap) {
-    if (b->pump_iq) hipHostFree(b->pump_iq);
-    b->pump_iq = NULL;
-    b->pump_cap = 0;
-    HIP_TRY(hipHostMalloc((void **)&b->pump_iq, need, hipHostMallocDefault));
-    b->pump_cap = need;
-  }
+  if (!b->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  int rc = pump_slot_reserve(b, p, nb);
+  if (rc) return rc;
   for (int s = 0; s < b->n_streams; s++) {
     fmd_ingest *g = b->ingest[s];
-    uint8_t *dst = b->pump_iq + (size_t)s * (size_t)nb * bl;
+    uint8_t *dst = p->h_iq + (size_t)s * (size_t)nb * bl;
     const uint32_t take = (uint32_t)nb * bl;
     pthread_mutex_lock(&g->m);
     uint32_t first = g->cap - g->rpos;
@@ -748,6 +780,44 @@ int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens) {
     g->size -= take;
     pthread_mutex_unlock(&g->m);
   }
-  int rc = fmd_batch_run_host(b, b->pump_iq, nb, pcm, lens);
-  return rc ? rc : nb;
+  const size_t slots = (size_t)b->n_streams * (size_t)nb;
+  HIP_TRY(hipMemcpyAsync(p->d_iq, p->h_iq, slots * bl, hipMemcpyHostToDevice, b->copy_stream));
+  HIP_TRY(hipEventRecord(p->h2d_done, b->copy_stream));
+  HIP_TRY(hipStreamWaitEvent(b->stream, p->h2d_done, 0));
+  rc = fmd_batch_run_device(b, p->d_iq, nb, p->d_pcm, p->d_lens, NULL);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(p->h_pcm, p->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipMemcpyDeviceToHost,
+                         b->stream));
+  HIP_TRY(hipMemcpyAsync(p->h_lens, p->d_lens, slots * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipEventRecord(p->done, b->stream));
+  p->n_blocks = nb;
+  b->pump_head ^= 1;
+  return nb;
+}
+
+/* Finish the oldest job begun: waits for it and copies its PCM and lengths out (layout as
+ * fmd_batch_run_host for that job's block count).  Returns the block count, 0 if none. */
+int fmd_batch_pump_end(fmd_batch *b, int16_t *pcm, int32_t *lens) {
+  if (!b || !pcm || !lens) return fail(FMD_E_ARG, "bad argument");
+  struct pump_slot *p = &b->pump[b->pump_tail];
+  if (p->n_blocks <= 0) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipEventSynchronize(p->done));
+  const size_t slots = (size_t)b->n_streams * (size_t)p->n_blocks;
+  memcpy(pcm, p->h_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t));
+  memcpy(lens, p->h_lens, slots * sizeof(int32_t));
+  const int nb = p->n_blocks;
+  p->n_blocks = 0;
+  b->pump_tail ^= 1;
+  return nb;
+}
+
+int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens) {
+  if (!b || !pcm || !lens || max_blocks <= 0) return fail(FMD_E_ARG, "bad argument");
+  if (b->pump[b->pump_tail].n_blocks > 0)
+    return fail(FMD_E_STATE, "jobs in flight: finish them with fmd_batch_pump_end");
+  const int nb = fmd_batch_pump_begin(b, max_blocks);
+  if (nb <= 0) return nb;
+  const int got = fmd_batch_pump_end(b, pcm, lens);
+  return got < 0 ? got : nb;
 }

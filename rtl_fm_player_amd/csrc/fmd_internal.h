@@ -25,9 +25,6 @@ typedef struct fmdk_params {
   float c_i, c_q;         /* fast path: constant terms of the folded offset      */
   float fm[128], fp[128], fs[128];
   float swf, cwf, lambda, coef;
-  float hm[96];           /* 90-tap stereo, fast: fm convolved with itself, first half (hm[m], m < 89), half the
-                             centre tap at [89] (it is applied to v + v), zeros above: L+R straight from the
-                             discriminator output through one 179-tap filter at the frame instants */
   float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
   int32_t size, half, mode;
   int32_t slow, fast;     /* rate_out2, rate_out                                 */

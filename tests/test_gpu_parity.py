@@ -253,6 +253,50 @@ def test_ingest_callback_and_pump(R):
         L.fmd_ingest_destroy(rings[s])
 
 
+def test_pipelined_pump_two_jobs_in_flight(R):
+    """fmd_batch_pump_begin/_end: two jobs queued back to back (the second is staged while the
+    first runs) give the same PCM as one sequential run: state is carried job to job."""
+    from oracle import OracleStream, lcg_bytes
+    L = R.lib()
+    ns, nb1, nb2 = 3, 2, 3
+    cfg = R.wbfm_config(math=R.MATH_EXACT, **CONFIGS["stereo_300k"])
+    b = R.BatchDemod(cfg, ns)
+    iqs = [lcg_bytes((nb1 + nb2) * BL, 4242 + s)[0] for s in range(ns)]
+    rings = []
+    for s in range(ns):
+        h = C.c_void_p()
+        assert L.fmd_ingest_create(C.byref(h), b._h, s, 0) == 0
+        rings.append(h)
+
+    def feed(s, lo, hi):
+        chunk = np.ascontiguousarray(iqs[s][lo:hi])
+        L.fmd_ingest_callback(chunk.ctypes.data, chunk.size, rings[s])
+
+    for s in range(ns):
+        feed(s, 0, nb1 * BL)
+    assert L.fmd_batch_pump_begin(b._h, 8) == nb1
+    for s in range(ns):
+        feed(s, nb1 * BL, (nb1 + nb2) * BL)
+    assert L.fmd_batch_pump_begin(b._h, 8) == nb2           # second job queued behind the first
+    assert L.fmd_batch_pump_begin(b._h, 8) < 0              # a third would need a slot: refused
+    outs = []
+    for nb in (nb1, nb2):
+        pcm = np.zeros((ns, nb, b.pcm_stride), dtype=np.int16)
+        lens = np.zeros((ns, nb), dtype=np.int32)
+        assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == nb
+        outs.append((pcm, lens))
+    pcm = np.zeros((ns, 1, b.pcm_stride), dtype=np.int16)
+    lens = np.zeros((ns, 1), dtype=np.int32)
+    assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == 0     # nothing left in flight
+    for s in range(ns):
+        want, wl = OracleStream(**CONFIGS["stereo_300k"]).run(iqs[s], BL)
+        got_l = np.concatenate([o[1][s] for o in outs])
+        assert np.array_equal(got_l, wl)
+        got = np.concatenate([o[0][s, k, :o[1][s, k]] for o in outs for k in range(o[1].shape[1])])
+        assert np.array_equal(got, want)
+        L.fmd_ingest_destroy(rings[s])
+
+
 def test_ingest_overflow_keeps_newest(R):
     L = R.lib()
     cfg = R.wbfm_config(math=R.MATH_EXACT, block_len=4096, **CONFIGS["mono_300k"])
