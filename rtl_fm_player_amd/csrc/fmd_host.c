@@ -225,6 +225,7 @@ static void fill_params(fmd_batch *b) {
   k->slow = c->rate_out2 > 0 ? c->rate_out2 : 1;
   k->fast = c->rate_out2 > 0 ? c->rate_out : 1;
   k->resample = c->rate_out2 > 0;
+  k->perm4 = k->resample && (4ll * k->fast) % k->slow == 0 && (((4ll * k->fast) / k->slow) & 1);
   k->deemph = c->deemph != 0;
   k->offset_tuning = c->offset_tuning != 0;
   /* restart distance for the de-emphasis recurrence: lambda^warm < 1e-12 */

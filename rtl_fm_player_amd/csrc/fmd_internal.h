@@ -36,6 +36,7 @@ typedef struct fmdk_params {
   int32_t pcm_stride;     /* int16 per (stream, block)                           */
   int32_t n_streams;
   int32_t n_chunks;       /* time chunks (workers) per stream                    */
+  int32_t perm4;          /* resampler: four frames are a whole, odd number of samples apart (lane map)   */
   int32_t warm_fast;      /* frames after which a zero de-emphasis state is right to 1e-9 */
   int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
 } fmdk_params;
