@@ -171,6 +171,24 @@ def test_variant_configs(R, lcg40, kw):
     assert np.array_equal(got[0], want)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(rate_in=300000, rate_out2=96000, mode=1, tau=750e-6),            # lambda = 0.986: lambda^16 = 0.80
+    dict(rate_in=300000, rate_out2=48000, mode=2, tau=300e-6),            # lambda = 0.933
+    dict(rate_in=300000, rate_out2=96000, mode=2, tau=75e-6),             # lambda = 0.870, 164 frames per tile
+])
+def test_slow_deemphasis(R, lcg40, kw):
+    """De-emphasis that decays slowly: the blocked recurrence of the fast kernels (scan over
+    16-frame groups) and the chunk warm-up lengths must hold for lambda close to 1."""
+    nb = 8
+    want, wlens, _ = oracle_run(kw, lcg40[: nb * BL])
+    got, lens, _ = gpu_run(R, kw, lcg40[: nb * BL], nb, R.MATH_EXACT)
+    assert np.array_equal(lens[0], wlens)
+    assert np.array_equal(got[0], want)
+    fast, flens, _ = gpu_run(R, kw, lcg40[: nb * BL], nb, R.MATH_FAST)
+    assert np.array_equal(flens[0], wlens)
+    assert np.abs(fast[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
 def test_synthetic_fm_stereo(R):
     """Integer-DDS stereo multiplex: exact bit-identical, fast within 1 LSB, and audible tones."""
     from oracle import dds_bytes
