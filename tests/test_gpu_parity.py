@@ -151,6 +151,20 @@ def test_ragged_block_lengths(R, lcg40, name, block_len):
     got, lens, _ = gpu_run(R, CONFIGS[name], iq, nb, R.MATH_EXACT, block_len=block_len)
     assert np.array_equal(lens[0], wlens)
     assert np.array_equal(got[0], want)
+    fast, flens, _ = gpu_run(R, CONFIGS[name], iq, nb, R.MATH_FAST, block_len=block_len)
+    assert np.array_equal(flens[0], wlens)
+    assert np.abs(fast[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("name", ["stereo_300k", "mono_300k"])
+def test_fast_state_carried_across_launches(R, lcg40, name):
+    """Fast kernels, 12 blocks as 1, 3 and 12 launches: the carried state (including the
+    de-emphasis state made by the blocked recurrence) keeps every split within 1 LSB."""
+    nb = 12
+    want, _, _ = oracle_run(CONFIGS[name], lcg40[: nb * BL])
+    for launches in (1, 3, 12):
+        got, _, _ = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, R.MATH_FAST, launches=launches)
+        assert np.abs(got[0].astype(np.int32) - want.astype(np.int32)).max() <= 1, launches
 
 
 @pytest.mark.parametrize("kw", [
