@@ -28,8 +28,12 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preheat", type=int, default=60,
+                    help="untimed launches before the warm-up steps so that at least this many launches precede the "
+                         "timed region: after idle the part needs ~40 launches (30 ms) to settle its clocks "
+                         "(tools/ramp_check.py: 0.76 ms per launch at first, 0.63 ms from then on)")
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
     ap.add_argument("--math", choices=["fast", "exact"], default="fast")
@@ -205,6 +209,8 @@ def main():
         parity = {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": 2}
         batch.reset()
 
+    for _ in range(max(0, args.preheat - args.warmup)):     # clock settling, see --preheat
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -258,6 +264,7 @@ def main():
                  "(rate_in 25k -> 12.5k PCM), IQ resident in HBM" % (S, B, BLOCK_LEN)),
                 "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
+                "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },
             "roofline": {
                 "bound": "hbm",

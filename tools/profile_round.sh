@@ -8,15 +8,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu $*"
+BENCH="python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu $*"
+PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --preheat 0 --no-cpu --no-check $*"   # counters serialise launches: few steps
 echo "== bench (unprofiled)"; $BENCH | tee $OUT/bench_unprofiled.json
 echo "== kernel trace + stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_traced.json 2>$OUT/trace.log
 echo "== pmc FETCH_SIZE"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-check > /dev/null 2>$OUT/pmc_fetch.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCBENCH > /dev/null 2>$OUT/pmc_fetch.log
 echo "== pmc WRITE_SIZE"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --no-check > /dev/null 2>$OUT/pmc_write.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCBENCH > /dev/null 2>$OUT/pmc_write.log
 echo "== pmc SQ"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- $BENCH --no-check > /dev/null 2>$OUT/pmc_sq.log
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $BENCH --no-check > /dev/null 2>$OUT/pmc_sq2.log
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq.log
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq2.log
 ls -R $OUT | head -40

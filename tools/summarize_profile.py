@@ -44,6 +44,10 @@ for f in find("trace/**/*kernel_trace.csv"):
          if "fmd_" in r["Kernel_Name"]]
     if d:
         out["kernel_trace_ms"] = {"n": len(d), "mean": sum(d) / len(d), "min": min(d), "max": max(d)}
+        steps = (out.get("bench_traced") or {}).get("steps")
+        if steps and len(d) >= steps:          # the timed steps are the last ones; the launches before them settle the clocks
+            t = d[-steps:]
+            out["kernel_trace_ms_timed_steps"] = {"n": len(t), "mean": sum(t) / len(t), "min": min(t), "max": max(t)}
         r0 = next(r for r in csv.DictReader(open(f)) if "fmd_" in r["Kernel_Name"])
         out["kernel_resources"] = {k: r0.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                                            "Scratch_Size", "Workgroup_Size", "Grid_Size")}
