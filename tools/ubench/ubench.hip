@@ -216,6 +216,9 @@ int main() {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   printf("device %s CUs %d clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
   const int cus = prop.multiProcessorCount;
+  /* settle the clocks first: after idle the part needs ~30 ms of work before its rates are steady */
+  for (int i = 0; i < 300; i++) hipLaunchKernelGGL(k_fma, dim3(cus), dim3(768), 0, 0, out, 1.0001f, 0.5f);
+  (void)hipDeviceSynchronize();
   for (int wpsimd : {1, 2, 4}) {
     int threads = 64 * 4 * wpsimd;  // one block per CU
     if (threads > 1024) continue;
