@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 BLOCK_LEN = 262144            # MAXIMUM_BUF_LENGTH, one reference block of u8 IQ
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3 # MI355X_MICROARCH.md: peak FP32 (vector), spec
 
 
 def parse():
@@ -241,6 +242,7 @@ def main():
 
     if rank == 0:
         copy_gbs = copy_bandwidth(torch, dev, stream) if S * B * BLOCK_LEN <= (1 << 31) else 0.0
+        flop_per_sample = 64 if stereo else 21
         value = total_samples / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -273,6 +275,12 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
+                # secondary roofline: the path is fp32-VALU-issue bound, not HBM bound;
+                # algorithmic flop per complex sample (stereo 64, mono / NFM 21) against the vector fp32 peak
+                "valu_fp32": {"flop_per_sample": flop_per_sample,
+                              "achieved_tflops": round(value * 1e6 * flop_per_sample / 1e12 / world, 2),
+                              "peak_tflops": VALU_FP32_PEAK_TFLOPS,
+                              "frac": round(value * 1e6 * flop_per_sample / 1e12 / world / VALU_FP32_PEAK_TFLOPS, 4)},
                 "copy_kernel_gbs": round(copy_gbs, 1),           # measured d2d copy on this device (read + write)
                 "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None,
                 "kernel_ms": round(kernel_ms, 4),

@@ -15,7 +15,9 @@ extern "C" {
 
 #define FMDK_TILE 512         /* rate_in samples per tile: 64 lanes x 8 outputs           */
 #define FMDK_WAVES 4          /* workers (wavefronts) per workgroup                       */
+#ifndef FMDK_FRAME_CAP
 #define FMDK_FRAME_CAP 512    /* pending resampler outputs (floats) per worker before a flush */
+#endif
 
 /* Uniform launch parameters, passed by value in the kernarg segment so that
  * tap reads with constant indices become scalar loads. */

@@ -34,6 +34,9 @@ def main():
     lens = torch.zeros((a.streams, a.blocks), dtype=torch.int32, device=dev)
     prof = torch.zeros((a.streams * 64, 16), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
+    for _ in range(60):                      # settle the clocks (tools/ramp_check.py)
+        b.run_device(iq, a.blocks, pcm, lens)
+    b.sync()
     ms = []
     for _ in range(a.reps):
         b.run_device(iq, a.blocks, pcm, lens)
