@@ -150,6 +150,25 @@ __global__ void k_perm(int *out, int sel) {
   int s = 0; for (int i = 0; i < 16; i++) s += acc[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// the MPX pattern with packed math: pairs of outputs share a tap (scalar, broadcast to both halves)
+__global__ void k_mpx_pk(float *out, float t0, float t1, float t2, float t3, float t4, float t5) {
+  f2 am[4], ap[4], as[4], x[6];
+  for (int i = 0; i < 4; i++) { am[i] = f2{(float)threadIdx.x + i, 1.f}; ap[i] = f2{(float)i, 2.f}; as[i] = f2{-(float)i, 3.f}; }
+  for (int i = 0; i < 6; i++) x[i] = f2{threadIdx.x * 0.001f + i, threadIdx.x * 0.002f - i};
+  const f2 T0 = {t0, t0}, T1 = {t1, t1}, T2 = {t2, t2}, T3 = {t3, t3}, T4 = {t4, t4}, T5 = {t5, t5};
+  for (int it = 0; it < ITERS / 2; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      f2 p = x[i] + x[i + 1];
+      am[i] = __builtin_elementwise_fma(p, T0, am[i]); ap[i] = __builtin_elementwise_fma(p, T1, ap[i]); as[i] = __builtin_elementwise_fma(p, T2, as[i]);
+      f2 q = x[i + 1] + x[i + 2];
+      am[i] = __builtin_elementwise_fma(q, T3, am[i]); ap[i] = __builtin_elementwise_fma(q, T4, ap[i]); as[i] = __builtin_elementwise_fma(q, T5, as[i]);
+    }
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+  }
+  f2 s = {0.f, 0.f}; for (int i = 0; i < 4; i++) s += am[i] + ap[i] + as[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
 // plain VOP2 ops with two VGPR sources
 __global__ void k_add2(float *out, float a) {
   float acc[16], x[16];
@@ -244,6 +263,8 @@ int main() {
     float d4 = time_kernel([&] { hipLaunchKernelGGL(k_dot4, dim3(cus), dim3(threads), 0, 0, (int *)out, 0x01020304, 0x7f80fe01, 0x10203040); });
     float pm = time_kernel([&] { hipLaunchKernelGGL(k_perm, dim3(cus), dim3(threads), 0, 0, (int *)out, 0x07020500); });
     printf("waves/SIMD %d: v_dot4_i32_i8 %.1f T lane-instr/s | v_perm_b32 %.1f\n", wpsimd, ops16 / d4 / 1e9, ops16 / pm / 1e9);
+    float mpk = time_kernel([&] { hipLaunchKernelGGL(k_mpx_pk, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
+    printf("waves/SIMD %d: mpx pattern, packed: %.1f T lane-op/s (same arithmetic as the plain pattern below)\n", wpsimd, ops8 / mpk / 1e9);
     printf("waves/SIMD %d: 8-byte encodings x4 %.1f x128 %.1f T lane-instr/s\n", wpsimd, ops8 / v4 / 1e9, ops8 / v128 / 1e9);
     printf("waves/SIMD %d: mpx pattern %.3f ms = %.1f T lane-instr/s | add vgpr,vgpr %.1f | fma vgpr,vgpr,vgpr %.1f | straight-line x4 %.1f x32 %.1f x128 %.1f\n", wpsimd, m8,
            ops8 / m8 / 1e9, ops16 / a2 / 1e9, ops16 / f3 / 1e9, ops8 / l4 / 1e9, ops8 / l32 / 1e9, ops8 / l128 / 1e9);
