@@ -209,8 +209,10 @@ static void fill_params(fmd_batch *b) {
     cq += (double)(sq * tap);
   }
   for (int j = 0; j < 16; j++) k->fbs[j] = b->taps.fb[j] / 128.0f;
-  k->c_i = (float)(-(127.5 / 128.0) * ci);
-  k->c_q = (float)(-(127.5 / 128.0) * cq);
+  /* the kernel converts the bytes as u - 128 (small signed integers: the partial sums then stay
+   * at signal level instead of carrying the 127.5 offset): (u - 127.5)/128 = (u - 128)/128 + 0.5/128 */
+  k->c_i = (float)((0.5 / 128.0) * ci);
+  k->c_q = (float)((0.5 / 128.0) * cq);
   k->swf = b->taps.swf;
   k->cwf = b->taps.cwf;
   k->lambda = c->deemph_lambda;

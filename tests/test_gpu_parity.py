@@ -460,3 +460,31 @@ def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode):
         got = np.concatenate([p[k, :l[k]] for k in range(B)])
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1, "seed %d: |diff| %d at %d" % (seeds[i], d.max(), int(d.argmax()))
+
+
+
+def test_fast_math_nfm_noise_next_to_the_origin(R):
+    """NFM on uniform noise (bench.py's generator and seed): stream 0 holds a decimated sample of
+    magnitude 1e-4, whose phase a 1e-7 rounding difference moves by 3 LSB of PCM; the fast kernels
+    redo samples that close to the origin in exact arithmetic."""
+    import torch
+    from oracle import OracleStream
+    S, B = 4, 16
+    kw = dict(rate_in=25000, rate_out2=12500, mode=1)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(12345)
+    iq = torch.randint(0, 256, (S, B, BL), dtype=torch.uint8, device=dev, generator=g)
+    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **kw), S)
+    pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+    lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    b.run_device(iq, B, pcm, lens)
+    b.sync()
+    for i in range(S):
+        want, wl = OracleStream(**kw).run(iq[i].cpu().numpy().reshape(-1), BL)
+        p, l = pcm[i].cpu().numpy(), lens[i].cpu().numpy()
+        assert np.array_equal(l, wl)
+        got = np.concatenate([p[k, :l[k]] for k in range(B)])
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1, "stream %d: |diff| %d at %d" % (i, d.max(), int(d.argmax()))
