@@ -169,6 +169,18 @@ __global__ void k_mpx_pk(float *out, float t0, float t1, float t2, float t3, flo
   f2 s = {0.f, 0.f}; for (int i = 0; i < 4; i++) s += am[i] + ap[i] + as[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
 }
+// signed-byte conversion (v_cvt_f32_i32 with an SDWA sign-extended byte select) against v_cvt_f32_ubyteN
+__global__ void k_cvt_s8(float *out, unsigned w) {
+  float acc[8]; unsigned x = w + threadIdx.x;
+  for (int i = 0; i < 8; i++) acc[i] = i;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc[i] += (float)(signed char)((x >> (8 * (i & 3))) & 0xff); }
+    x = x * 1664525u + 1013904223u;
+  }
+  float s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // plain VOP2 ops with two VGPR sources
 __global__ void k_add2(float *out, float a) {
   float acc[16], x[16];
@@ -265,6 +277,9 @@ int main() {
     printf("waves/SIMD %d: v_dot4_i32_i8 %.1f T lane-instr/s | v_perm_b32 %.1f\n", wpsimd, ops16 / d4 / 1e9, ops16 / pm / 1e9);
     float mpk = time_kernel([&] { hipLaunchKernelGGL(k_mpx_pk, dim3(cus), dim3(threads), 0, 0, out, 1.0001f, 0.5f, 0.25f, 0.3f, 0.7f, 0.9f); });
     printf("waves/SIMD %d: mpx pattern, packed: %.1f T lane-op/s (same arithmetic as the plain pattern below)\n", wpsimd, ops8 / mpk / 1e9);
+    float cu = time_kernel([&] { hipLaunchKernelGGL(k_cvt, dim3(cus), dim3(threads), 0, 0, out, 12345u); });
+    float cs = time_kernel([&] { hipLaunchKernelGGL(k_cvt_s8, dim3(cus), dim3(threads), 0, 0, out, 12345u); });
+    printf("waves/SIMD %d: cvt ubyte + add %.1f | cvt signed byte (sdwa) + add %.1f T lane-instr/s\n", wpsimd, ops16 / cu / 1e9, ops16 / cs / 1e9);
     printf("waves/SIMD %d: 8-byte encodings x4 %.1f x128 %.1f T lane-instr/s\n", wpsimd, ops8 / v4 / 1e9, ops8 / v128 / 1e9);
     printf("waves/SIMD %d: mpx pattern %.3f ms = %.1f T lane-instr/s | add vgpr,vgpr %.1f | fma vgpr,vgpr,vgpr %.1f | straight-line x4 %.1f x32 %.1f x128 %.1f\n", wpsimd, m8,
            ops8 / m8 / 1e9, ops16 / a2 / 1e9, ops16 / f3 / 1e9, ops8 / l4 / 1e9, ops8 / l32 / 1e9, ops8 / l128 / 1e9);
