@@ -11,6 +11,7 @@ used only to gather the per-rank counters.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import threading
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--data", choices=["fm", "noise"], default="fm",
+                    help="fm: synthetic FM broadcast per stream (stereo multiplex with 19 kHz pilot and L-R DSB, "
+                         "BASELINE.json configs[1..3]; NFM: 1 kHz tone, 5 kHz deviation); noise: uniform random bytes")
     return ap.parse_args()
 
 
@@ -136,6 +140,39 @@ def copy_bandwidth(torch, dev, stream, nbytes=1 << 30):
     return best
 
 
+def synth_fm_iq(torch, dev, n_streams, n_samples, fs, wide, seed):
+    """u8 IQ of n_streams synthetic FM stations, made on the device (float64 phase, reproducible).
+
+    Wide FM: stereo multiplex 0.45 (L+R) + 0.45 (L-R) sin(2 w_p t) + 0.1 sin(w_p t), w_p = 19 kHz pilot,
+    L / R tones per stream, +-75 kHz deviation.  Narrow FM: one tone, +-5 kHz.  The carrier sits at
+    -fs/4 (rotate_90_u8_f32 centres it), amplitude 100 LSB around 127.5, +-2 LSB of uniform noise.
+    """
+    out = torch.empty((n_streams, 2 * n_samples), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = torch.arange(n_samples, dtype=torch.float64, device=dev)
+    quarter = (torch.arange(n_samples, device=dev) % 4).to(torch.float64) * (-math.pi / 2)   # -fs/4, exact per sample
+    two_pi = 2.0 * math.pi
+    for s in range(n_streams):
+        k = seed * 131 + s
+        f_l, f_r = 400.0 + 37.0 * (k % 97), 1000.0 + 53.0 * (k % 89)
+        if wide:
+            left, right = torch.sin(two_pi * f_l / fs * n), torch.sin(two_pi * f_r / fs * n)
+            pilot = two_pi * 19000.0 / fs * n
+            mpx = 0.45 * (left + right) + 0.45 * (left - right) * torch.sin(2.0 * pilot) + 0.1 * torch.sin(pilot)
+            dev_hz = 75000.0
+        else:
+            mpx = torch.sin(two_pi * f_l / fs * n)
+            dev_hz = 5000.0
+        phase = torch.cumsum(mpx, 0) * (two_pi * dev_hz / fs) + quarter
+        noise = torch.rand((2, n_samples), dtype=torch.float64, device=dev, generator=g) * 4.0 - 2.0
+        i = torch.clamp(torch.round(127.5 + 100.0 * torch.cos(phase) + noise[0]), 0, 255)
+        q = torch.clamp(torch.round(127.5 + 100.0 * torch.sin(phase) + noise[1]), 0, 255)
+        out[s, 0::2] = i.to(torch.uint8)
+        out[s, 1::2] = q.to(torch.uint8)
+    return out
+
+
 def measured_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
     gfx950 correction + WRITE_SIZE, tools/profile_round.sh) when one exists for this workload."""
@@ -182,7 +219,11 @@ def main():
     # synthetic IQ resident in HBM: uniform random bytes, per-rank seed
     g = torch.Generator(device=dev)
     g.manual_seed(12345 + rank)
-    iq = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=g)
+    if args.data == "noise":
+        iq = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        iq = synth_fm_iq(torch, dev, S, B * BLOCK_LEN // 2, 200e3 if args.mode == "nfm" else 2.4e6,
+                         args.mode != "nfm", 12345 + rank).view(S, B, BLOCK_LEN)
     pcm = torch.zeros((S, B, batch.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
     stream = torch.cuda.Stream(device=dev)          # kernels and timing events share this stream
@@ -257,7 +298,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": ("synthetic FM broadcast per stream (stereo multiplex: 19 kHz pilot + L-R DSB, tones, +-75 kHz)"
+                     if args.data == "fm" and args.mode != "nfm" else
+                     "synthetic narrow FM per stream (tone, +-5 kHz)" if args.data == "fm" else
+                     "synthetic uniform random bytes"),
             "config": {
                 "workload": ("%d concurrent 2.4 Msps %s WBFM streams per GPU x %d blocks of %d B u8 IQ "
                              "(rate_in 300k -> 48k PCM), IQ resident in HBM" % (S, args.mode, B, BLOCK_LEN))
