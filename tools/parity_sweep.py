@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py's parity gate for every rank of an 8-GPU run, on one GPU: same generator, seeds
+"""bench.py's parity gate for every rank of an 8-GPU run, on one GPU: same generator (SWEEP_DATA=fm|noise), seeds
 12345 + rank, streams 0 and (7 rank + S/3) % S, all three modes, fast math.  Prints the worst
 |diff| per (mode, rank); anything above 1 would abort that rank's bench."""
 import os
@@ -24,9 +24,14 @@ for name, kw in MODES.items():
     pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
     for rank in ranks:
-        g = torch.Generator(device=dev)
-        g.manual_seed(12345 + rank)
-        iq = torch.randint(0, 256, (S, B, BL), dtype=torch.uint8, device=dev, generator=g)
+        if os.environ.get("SWEEP_DATA", "fm") == "noise":
+            g = torch.Generator(device=dev)
+            g.manual_seed(12345 + rank)
+            iq = torch.randint(0, 256, (S, B, BL), dtype=torch.uint8, device=dev, generator=g)
+        else:                                          # bench.py's default input
+            import bench
+            iq = bench.synth_fm_iq(torch, dev, S, B * BL // 2, 200e3 if name == "nfm" else 2.4e6, name != "nfm",
+                                   12345 + rank).view(S, B, BL)
         torch.cuda.synchronize()          # iq is made on torch's stream, the kernel runs on the batch's own
         b.reset()
         b.run_device(iq, B, pcm, lens)
