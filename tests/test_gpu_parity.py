@@ -488,3 +488,38 @@ def test_fast_math_nfm_noise_next_to_the_origin(R):
         got = np.concatenate([p[k, :l[k]] for k in range(B)])
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1, "stream %d: |diff| %d at %d" % (i, d.max(), int(d.argmax()))
+
+
+@pytest.mark.parametrize("mode", ["stereo", "nfm"])
+def test_bench_fm_input(R, mode):
+    """bench.py's synthetic FM broadcasts (stereo multiplex with pilot / narrow FM): exact kernels
+    bit-identical, fast kernels within 1 LSB, and the stereo decode is doing something (L != R)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import OracleStream
+    S, B = 3, 6
+    nfm = mode == "nfm"
+    kw = dict(rate_in=25000, rate_out2=12500, mode=1) if nfm else dict(rate_in=300000, rate_out2=48000, mode=2)
+    dev = torch.device("cuda:0")
+    iq = bench.synth_fm_iq(torch, dev, S, B * BL // 2, 200e3 if nfm else 2.4e6, not nfm, 777).view(S, B, BL)
+    host = iq.cpu().numpy()
+    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+        b = R.BatchDemod(R.wbfm_config(math=math, **kw), S)
+        pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+        lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        b.run_device(iq, B, pcm, lens)
+        b.sync()
+        for i in range(S):
+            want, wl = OracleStream(**kw).run(host[i].reshape(-1), BL)
+            p, l = pcm[i].cpu().numpy(), lens[i].cpu().numpy()
+            assert np.array_equal(l, wl)
+            got = np.concatenate([p[k, :l[k]] for k in range(B)])
+            assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= tol
+            if not nfm and math == R.MATH_EXACT:
+                left, right = got[4000::2].astype(np.float64), got[4001::2].astype(np.float64)
+                assert left.std() > 200 and right.std() > 200 and np.abs(left - right).std() > 100
+
