@@ -238,6 +238,10 @@ int fmd_batch_reset(fmd_batch *b);
 /* Duration of the most recent fmd_batch_run_device kernel, measured with HIP
  * events recorded on the stream the kernel was launched on (synchronises). */
 int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms);
+/* Every launch is bracketed by an event pair for fmd_batch_last_kernel_ms; a caller that
+ * launches back to back and times the whole run itself can turn that off (on = 0): the two
+ * event records cost about 10 us of GPU time per launch. */
+int fmd_batch_set_timing(fmd_batch *b, int on);
 /* Name of the dominant kernel (as rocprofv3 reports it) for this batch. */
 const char *fmd_batch_kernel_name(const fmd_batch *b);
 

@@ -95,7 +95,7 @@ _EXPORTS = [
     "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
     "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_run_device", "fmd_batch_run_device_debug",
     "fmd_batch_sync", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
-    "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_kernel_name", "fmd_last_error",
+    "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
     "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_batch_pump",
     "fmd_batch_pump_begin", "fmd_batch_pump_end",
@@ -141,6 +141,7 @@ def lib():
     L.fmd_batch_set_state.argtypes = [vp, C.c_int, C.POINTER(FmdStreamState)]
     L.fmd_batch_reset.argtypes = [vp]
     L.fmd_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fmd_batch_set_timing.argtypes = [vp, C.c_int]
     L.fmd_batch_kernel_name.argtypes = [vp]
     L.fmd_batch_kernel_name.restype = C.c_char_p
     L.fmd_last_error.restype = C.c_char_p
@@ -256,6 +257,10 @@ class BatchDemod:
         pcm, lens = self.run_host(iq, n_blocks)
         out = [np.concatenate([pcm[s, b, :lens[s, b]] for b in range(n_blocks)]) for s in range(self.n_streams)]
         return out, lens
+
+    def set_timing(self, on):
+        """Bracket every launch with an event pair (default) or not; see fmd_batch_set_timing."""
+        _check(lib().fmd_batch_set_timing(self._h, int(bool(on))), "fmd_batch_set_timing")
 
     def last_kernel_ms(self):
         ms = C.c_float()

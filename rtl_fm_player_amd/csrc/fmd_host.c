@@ -155,6 +155,7 @@ struct fmd_batch {
   int pcm_stride;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
+  int no_timing;               /* fmd_batch_set_timing(b, 0): no event pair around the kernel */
   int timed;
   void *d_state[2];            /* fmd_stream_state[n_streams], ping-pong: a multi-chunk launch
                                   reads one and writes the other                        */
@@ -360,13 +361,13 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
     if (want > 1) kp.n_chunks = (int)want;
   }
   const int nxt = (kp.n_chunks > 1) ? (b->cur ^ 1) : b->cur;
-  HIP_TRY(hipEventRecord(b->ev0, st));
+  if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev0, st));
   int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state[b->cur],
                       b->d_state[nxt], dbg, st);
   if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
-  HIP_TRY(hipEventRecord(b->ev1, st));
+  if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev1, st));
   b->cur = nxt;
-  b->timed = 1;
+  b->timed = !b->no_timing;
   return FMD_OK;
 }
 
@@ -387,6 +388,13 @@ int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms) {
   if (!b->timed) return fail(FMD_E_STATE, "no kernel has been launched yet");
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+  return FMD_OK;
+}
+
+int fmd_batch_set_timing(fmd_batch *b, int on) {
+  if (!b) return fail(FMD_E_ARG, "NULL batch");
+  b->no_timing = !on;
+  if (!on) b->timed = 0;
   return FMD_OK;
 }
 
