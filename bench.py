@@ -80,13 +80,19 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg_kw, seconds):
+def cpu_baseline(cfg_kw, seconds, iq_dev=None):
     """The oracle (a bit-exact CPU port of the reference path) on this host's cores:
-    one independent stream per thread, bounded sample of the same workload."""
+    one independent stream per thread, bounded sample of the same workload (the first 8 blocks
+    of the GPU run's own streams when they are handed in)."""
     from oracle import OracleStream, lcg_bytes
     n_thr = usable_cores()
     nb = 8
-    iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
+    if iq_dev is not None and iq_dev.shape[1] >= nb:
+        iqs = [np.ascontiguousarray(iq_dev[t % iq_dev.shape[0], :nb].cpu().numpy().reshape(-1)) for t in range(n_thr)]
+        what = "the run's own IQ"
+    else:
+        iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
+        what = "LCG u8 IQ"
     streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
     streams[0].run(iqs[0], BLOCK_LEN)                      # page in / warm up
     t1 = time.perf_counter()                               # SURVEY 8(d): 1 thread x 1 stream as well
@@ -115,8 +121,8 @@ def cpu_baseline(cfg_kw, seconds):
         "kind": "port",
         "single_thread": round(single, 2),
         "sample": "%d threads (affinity capped by the cgroup CPU quota) x independent streams on %s, %d-block "
-                  "runs of LCG u8 IQ for %.0f s (oracle/fm_oracle.c, -O3 -ffp-contract=off)"
-                  % (n_thr, cpu_model(), nb, dt),
+                  "runs of %s for %.0f s (oracle/fm_oracle.c, -O3 -ffp-contract=off)"
+                  % (n_thr, cpu_model(), nb, what, dt),
     }
 
 
@@ -342,7 +348,7 @@ def main():
         if parity:
             out["parity"] = parity
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds, iq)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
