@@ -2,6 +2,10 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  The product package (rtl_fm_player_amd) never does.
+
+oracle/_ref/ (built by build_ref.py from /root/reference where it lies, git-ignored) holds the
+reference's own hot path as a shared library; refbind.py binds it for the pin tests, the fixture
+generator and bench.py's cpu_baseline leg.
 """
 from .fmo import (  # noqa: F401
     FmoConfig,

@@ -21,13 +21,18 @@
  *   f32 -> s16                  src/rtl_fm_player.c:711-735
  *   chain order (full_demod)    src/rtl_fm_player.c:758-788
  *
- * Parity pin: the reference has no tests and cannot be rebuilt in this image
- * (src/rtl_fm_player.c needs <libusb.h> and <SDL2/SDL.h>, both absent, and
- * writing stand-in headers is not allowed).  The oracle is therefore pinned
- * to the known answers the survey recorded from the reference itself
- * (five 64-bit hashes over 40 blocks each, the first
- * block lengths, and the tap / scalar constants in hex-float form); see
- * tests/test_oracle_pin.py.
+ * Parity pin: PINNED TO THE REFERENCE ITSELF.  oracle/build_ref.py compiles the
+ * reference's hot path (src/rtl_fm_player.c:195-788 and the type / table lines of
+ * include/rtl_fm_player.h it needs) from the sources where they lie into
+ * oracle/_ref/libref.so - no stand-in headers, nothing of the reference in this
+ * repository - and tests/test_ref_pin.py holds this restatement against it bit
+ * for bit: PCM, block lengths, per-stage intermediates, carried state and filter
+ * tables on the five survey configurations (whose recorded hashes libref.so also
+ * reproduces), nine further configurations, FM-broadcast input and a 100-case
+ * configuration fuzz with ragged block lengths.  tests/golden/ref_vectors.npz
+ * holds reference outputs (tests/golden/make_ref_fixtures.py) for boxes without
+ * /root/reference; tests/test_golden_vectors.py checks the oracle and, directly,
+ * the HIP path against them.
  *
  * Build: -O3 -ffp-contract=off, no -ffast-math, no -march (the reference's
  * CMake Release build has no FMA contraction).
