@@ -8,11 +8,21 @@ IQ: `--streams` independent 2.4 Msps wide-FM stereo streams per GPU (default
 256, BASELINE.json configs[2]) x `--blocks` reference blocks of 262144 bytes.
 Streams shard across GPUs with no data-path collective (weak scaling); RCCL is
 used only to gather the per-rank counters.  Rank 0 prints ONE JSON line.
+
+N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` the ranks are already there (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment; --gpus must equal WORLD_SIZE).  Run plainly as `python bench.py --gpus N`,
+this process becomes a launcher: BEFORE importing torch or touching HIP it starts N fresh
+children of itself with those variables set, forwards rank 0's JSON line and exits
+non-zero if any child fails (never an exec: a process that has initialised the GPU must
+not be replaced).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -44,6 +54,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the H2D-inclusive leg (e2e_h2d)")
+    ap.add_argument("--e2e-streams", type=int, default=64)
+    ap.add_argument("--e2e-jobs", type=int, default=10)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / counter-gather plumbing only: no GPU work, gloo instead of RCCL (CPU tests)")
     ap.add_argument("--data", choices=["fm", "noise"], default="fm",
                     help="fm: synthetic FM broadcast per stream (stereo multiplex with 19 kHz pilot and L-R DSB, "
                          "BASELINE.json configs[1..3]; NFM: 1 kHz tone, 5 kHz deviation); noise: uniform random bytes")
@@ -80,11 +95,33 @@ def cpu_model():
     return "unknown"
 
 
+CPU_CONFIGS = {   # BASELINE.json configs[0], [1], [4]
+    "mono_2.4Msps": dict(rate_in=300000, rate_out2=48000, mode=1),
+    "stereo_2.4Msps": dict(rate_in=300000, rate_out2=48000, mode=2),
+    "nfm_200ksps": dict(rate_in=25000, rate_out2=12500, mode=1),
+}
+
+
+def _cpu_stream_factory():
+    """The CPU side that is timed: oracle/_ref/libref.so - the reference's own full_demod()
+    compiled from its sources by oracle/build_ref.py (kind "reference") - when it was built,
+    otherwise the bit-exact restatement oracle/fm_oracle.c (kind "port")."""
+    try:
+        from oracle import refbind
+        if refbind.have_ref():
+            return refbind.RefStream, "reference", "oracle/_ref/libref.so = the reference's rotate_90_u8_f32 + full_demod, gcc -O3"
+    except Exception:                       # noqa: BLE001 - any problem with the optional library: use the port
+        pass
+    from oracle import OracleStream
+    return OracleStream, "port", "oracle/fm_oracle.c, -O3 -ffp-contract=off"
+
+
 def cpu_baseline(cfg_kw, seconds, iq_dev=None):
-    """The oracle (a bit-exact CPU port of the reference path) on this host's cores:
-    one independent stream per thread, bounded sample of the same workload (the first 8 blocks
-    of the GPU run's own streams when they are handed in)."""
-    from oracle import OracleStream, lcg_bytes
+    """The reference's CPU full_demod() on this host's cores: one independent stream per thread
+    on a bounded sample of the same workload (the first 8 blocks of the GPU run's own streams),
+    plus 1 thread x 1 stream for each of BASELINE.json's single-stream configurations."""
+    from oracle import lcg_bytes
+    make, kind, what_lib = _cpu_stream_factory()
     n_thr = usable_cores()
     nb = 8
     if iq_dev is not None and iq_dev.shape[1] >= nb:
@@ -93,14 +130,21 @@ def cpu_baseline(cfg_kw, seconds, iq_dev=None):
     else:
         iqs = [lcg_bytes(nb * BLOCK_LEN, 12345 + t)[0] for t in range(n_thr)]
         what = "LCG u8 IQ"
-    streams = [OracleStream(**cfg_kw) for _ in range(n_thr)]
+    streams = [make(**cfg_kw) for _ in range(n_thr)]
     streams[0].run(iqs[0], BLOCK_LEN)                      # page in / warm up
-    t1 = time.perf_counter()                               # 1 thread x 1 stream as well
-    n1 = 0
-    while time.perf_counter() - t1 < min(2.0, seconds / 4):
-        streams[0].run(iqs[0], BLOCK_LEN)
-        n1 += nb * BLOCK_LEN // 2
-    single = n1 / (time.perf_counter() - t1) / 1e6
+
+    def one_thread(kw, budget):
+        st = make(**kw)
+        st.run(iqs[0], BLOCK_LEN)
+        t1, n1 = time.perf_counter(), 0
+        while time.perf_counter() - t1 < budget:
+            st.run(iqs[0], BLOCK_LEN)
+            n1 += nb * BLOCK_LEN // 2
+        return round(n1 / (time.perf_counter() - t1) / 1e6, 2)
+
+    per_cfg = min(2.0, seconds / 6)
+    configs = {name: one_thread(kw, per_cfg) for name, kw in CPU_CONFIGS.items()}   # 1 thread x 1 stream
+    single = one_thread(cfg_kw, per_cfg)
     done = [0] * n_thr
     stop = time.perf_counter() + seconds
 
@@ -118,12 +162,73 @@ def cpu_baseline(cfg_kw, seconds, iq_dev=None):
         "value": round(sum(done) / dt / 1e6, 2),
         "unit": "Msamples/s",
         "cores": n_thr,
-        "kind": "port",
-        "single_thread": round(single, 2),
+        "kind": kind,
+        "single_thread": single,
+        "configs_single_thread": configs,
         "sample": "%d threads (affinity capped by the cgroup CPU quota) x independent streams on %s, %d-block "
-                  "runs of %s for %.0f s (oracle/fm_oracle.c, -O3 -ffp-contract=off)"
-                  % (n_thr, cpu_model(), nb, what, dt),
+                  "runs of %s for %.0f s (%s); configs_single_thread: 1 thread x 1 stream, %.1f s each"
+                  % (n_thr, cpu_model(), nb, what, dt, what_lib, per_cfg),
     }
+
+
+def e2e_h2d(R, torch, cfg, iq_dev, n_streams, n_blocks, n_jobs, device):
+    """IQ that starts in HOST memory: rtlsdr-callback-shaped ingest (fmd_ingest_callback, one
+    262144-byte transfer at a time, fed by host threads as the dongle threads would) -> pinned
+    rings -> fmd_batch_pump_begin / _end with two jobs in flight (staging + H2D of job k+1 beside
+    the kernel of job k) -> PCM back in host memory.  Wall clock over everything, first callback to
+    last PCM.  Roles: src/rtl_fm_player.c:790-837 (callback), :855-933 (demod thread)."""
+    import ctypes as C
+    L = R.lib()
+    b = R.BatchDemod(cfg, n_streams, device=device)
+    host = np.ascontiguousarray(iq_dev[:n_streams, :n_blocks].cpu().numpy()).reshape(n_streams, n_blocks, BLOCK_LEN)
+    rings = []
+    for s in range(n_streams):
+        h = C.c_void_p()
+        rc = L.fmd_ingest_create(C.byref(h), b._h, s, 0)
+        if rc:
+            raise RuntimeError("fmd_ingest_create: %d" % rc)
+        rings.append(h)
+    n_thr = max(1, min(usable_cores(), n_streams, 16))
+
+    def feed(t):
+        for s in range(t, n_streams, n_thr):
+            for k in range(n_blocks):
+                L.fmd_ingest_callback(host[s, k].ctypes.data, BLOCK_LEN, rings[s])
+
+    def fill():
+        thr = [threading.Thread(target=feed, args=(t,)) for t in range(n_thr)]
+        [x.start() for x in thr]
+        [x.join() for x in thr]
+
+    pcm = np.zeros((n_streams, n_blocks, b.pcm_stride), dtype=np.int16)
+    lens = np.zeros((n_streams, n_blocks), dtype=np.int32)
+
+    def run(jobs):
+        fill()
+        assert L.fmd_batch_pump_begin(b._h, n_blocks) == n_blocks, L.fmd_last_error()
+        for _ in range(1, jobs):
+            fill()                                              # overlaps the job in flight
+            assert L.fmd_batch_pump_begin(b._h, n_blocks) == n_blocks, L.fmd_last_error()
+            assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == n_blocks
+        assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == n_blocks
+
+    run(2)                                                      # buffers allocated, clocks up
+    t0 = time.perf_counter()
+    run(n_jobs)
+    dt = time.perf_counter() - t0
+    nbytes = n_jobs * n_streams * n_blocks * BLOCK_LEN
+    out = {
+        "value": round(nbytes / 2 / dt / 1e6, 1), "unit": "Msamples/s",
+        "pcie_gbs": round(nbytes / dt / 1e9, 2),
+        "streams": n_streams, "blocks_per_job": n_blocks, "jobs": n_jobs, "feeder_threads": n_thr,
+        "ms_per_job": round(dt / n_jobs * 1e3, 3),
+        "path": "host IQ -> fmd_ingest_callback (262144-byte transfers, %d host threads) -> pinned rings -> "
+                "fmd_batch_pump_begin/_end, two jobs in flight -> PCM in host memory; wall clock" % n_thr,
+    }
+    for h in rings:
+        L.fmd_ingest_destroy(h)
+    b.close()
+    return out
 
 
 def copy_bandwidth(torch, dev, stream, nbytes=1 << 30):
@@ -194,16 +299,78 @@ def measured_traffic(config):
     return best
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no rank environment: start N fresh ranks of this script.
+    Nothing here imports torch or touches HIP except a device COUNT, which does not initialise
+    the GPU; the children are new processes (subprocess), never an exec of this one."""
+    n = args.gpus
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py: --gpus %d but this node shows %d HIP device(s)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("bench.py: rank exit codes %s" % codes)
+    if not any(l.startswith("{") for l in out0.splitlines()):
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+
+
+def dry_run(args, rank, world):
+    """The N-rank plumbing without a GPU (tests/test_bench_launcher.py): gloo, invented counters."""
+    import torch
+    import torch.distributed as dist
+    from rtl_fm_player_amd.shard import gather_counters, shard_streams
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard_streams(args.streams * world, world, rank)
+    samples = count * args.blocks * (BLOCK_LEN // 2) * args.steps
+    rep = gather_counters(dist if world > 1 else None, torch.device("cpu"), 1.0 + 0.25 * rank, samples,
+                          1000 + rank, first)
+    if rank == 0:
+        print(json.dumps({"metric": "IQ Msamples/s through full_demod", "dry_run": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "value": rep["samples"] / rep["elapsed_s"] / 1e6,
+                          "unit": "Msamples/s", "scaling": "weak", "per_rank": rep["per_rank"]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
-    import torch
-    import rtl_fm_player_amd as R
-
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU "
+                         "(torch.distributed.run --nproc-per-node %d) or run `python bench.py --gpus %d` by itself"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    import torch
+    import rtl_fm_player_amd as R
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s)" % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -347,10 +514,13 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if parity:
             out["parity"] = parity
+        out["per_rank"] = rep["per_rank"]                      # samples, kernel ns per launch, PCM checksum of each rank
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds, iq)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
+        if not args.no_e2e and world == 1:
+            out["e2e_h2d"] = e2e_h2d(R, torch, cfg, iq, min(args.e2e_streams, S), B, args.e2e_jobs, local)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
