@@ -45,6 +45,8 @@ extern "C" {
 #define FMD_MAXIMUM_BUF_LENGTH (FMD_MAXIMUM_OVERSAMPLE * FMD_DEFAULT_BUF_LENGTH) /* :33 */
 
 #ifndef FMD_NO_REFERENCE_TYPES
+/* pthread_rwlock_t is POSIX.1-2001: compile with -std=gnu11 (the reference's CMake default dialect)
+ * or define _POSIX_C_SOURCE >= 200112L / _GNU_SOURCE before the first include under strict -std=c11 */
 #include <pthread.h>
 
 struct output_state;
@@ -121,7 +123,17 @@ struct demod_state {      /* include/rtl_fm_player.h:127-175 */
  * mutable state field back into *d (lowpass_tb, pre_*_f32, lpr rings/pos/pp,
  * prev_lpr_index, deemph_*_f32), so CPU and GPU calls can be interleaved on
  * one struct.  They return void like the originals; an unusable device or an
- * unsupported configuration aborts with a message on stderr. */
+ * unsupported configuration aborts with a message on stderr.
+ *
+ * Limits of this surface (it serves one dongle, like the program it drops into; many streams
+ * belong on the batch API below):
+ *   - every block pays three synchronous round trips (state up, IQ up + PCM down, state down);
+ *   - the device side of a struct is found through a registry keyed by the struct's address
+ *     (the reference struct has no spare field): at most 64 demod_state objects at a time, a
+ *     65th aborts; fmd_demod_release (or deinit_lp_real_f32) frees a slot;
+ *   - the arithmetic contract is read ONCE, at the first full_demod of the process, from the
+ *     environment: FMD_MATH_FAST set -> +-1 LSB kernels, otherwise the bit-exact ones;
+ *   - any HIP error is fatal (abort), because the signatures have no way to report it. */
 void init_u8_f32_table(void);                       /* src/rtl_fm_player.c:195 */
 void init_lp_f32(void);                             /* :241 */
 void init_lp_real_f32(struct demod_state *fm);      /* :413 */
@@ -212,6 +224,11 @@ void fmd_batch_destroy(fmd_batch *b);
 int fmd_batch_pcm_stride(const fmd_batch *b);
 int fmd_batch_n_streams(const fmd_batch *b);
 
+/* fmd_batch_destroy waits for everything the batch has queued (on its own streams and on the
+ * caller's stream of the most recent launch, which must therefore still exist) and detaches the
+ * ingest rings bound to it: they stay valid and are destroyed by their owner with
+ * fmd_ingest_destroy, before or after the batch. */
+
 /* Device-resident run.  Layouts (all device pointers):
  *   d_iq   u8  [n_streams][n_blocks][block_len]
  *   d_pcm  s16 [n_streams][n_blocks][pcm_stride]
@@ -219,7 +236,12 @@ int fmd_batch_n_streams(const fmd_batch *b);
  * hip_stream: a hipStream_t passed as void* (NULL = the batch's own stream).
  * d_iq must be 16-byte aligned.  Asynchronous; state advances by n_blocks blocks
  * per stream.  Internally each stream's tiles are cut into time chunks so that
- * every CU holds 8 workers; results do not depend on that. */
+ * every CU holds 12 workers; results do not depend on that.
+ * Stream rule: a batch's launches form ONE sequence (each reads the state the one before
+ * wrote).  They may be queued on different streams - the library inserts the event wait when
+ * the stream changes between two launches - but calls on one fmd_batch must come from one
+ * thread at a time, and a caller's stream must outlive the work queued on it.  get_state /
+ * set_state / reset / sync / destroy wait for the most recent launch whatever stream it is on. */
 int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
                          void *d_lens, void *hip_stream);
 int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
@@ -253,30 +275,48 @@ int fmd_device_count(void);
  * ------------------------------------------------------------------------
  * fmd_ingest_callback has the exact rtlsdr_read_async_cb_t signature
  * (reference include/rtl-sdr.h:340) and the contract of rtlsdr_callback
- * (src/rtl_fm_player.c:790-837): it copies `len` bytes before returning,
- * never blocks on the GPU, and on overflow keeps the newest data and counts
- * the drop.  ctx is an fmd_ingest* bound to one stream of a batch. */
+ * (src/rtl_fm_player.c:790-837): it copies `len` bytes before returning and
+ * never blocks on the GPU.  ctx is an fmd_ingest* bound to one stream of a batch.
+ * The ring is pinned memory and is itself the source of the H2D copies.
+ *
+ * Overflow.  DEFAULT IS NOT THE REFERENCE'S: FMD_OVERFLOW_DROP_OLDEST splits a copy at the end
+ * of the ring and, when the ring is full, advances the read position over the oldest bytes (a clean
+ * loss, counted).  The reference instead restarts a transfer that does not fit before the end of
+ * the ring at offset 0 and, on overflow, clamps its byte count without moving the read position, so
+ * the demod thread then reads new data where old was expected (src/rtl_fm_player.c:813-834).
+ * FMD_OVERFLOW_REFERENCE reproduces exactly that, for callers that want identical behaviour. */
+#define FMD_OVERFLOW_DROP_OLDEST 0
+#define FMD_OVERFLOW_REFERENCE 1
 typedef struct fmd_ingest fmd_ingest;
 typedef void (*fmd_read_async_cb_t)(unsigned char *buf, uint32_t len, void *ctx);
 
+/* ring_bytes 0: the reference's 4 MiB (16 blocks).  b == NULL makes an unbound ring in ordinary
+ * host memory (no device needed; `stream` ignored) that its owner drains with fmd_ingest_pop. */
 int fmd_ingest_create(fmd_ingest **out, fmd_batch *b, int stream, uint32_t ring_bytes);
 void fmd_ingest_destroy(fmd_ingest *g);
+int fmd_ingest_set_overflow(fmd_ingest *g, int mode);
 void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx);
-/* Bytes currently buffered / dropped so far. */
+/* Bytes buffered that no job has taken yet / bytes dropped so far.  Thread-safe, like the callback
+ * and fmd_ingest_mute: the callback may run on any thread (librtlsdr's event thread in the reference)
+ * while another thread pumps. */
 uint32_t fmd_ingest_buffered(const fmd_ingest *g);
 uint64_t fmd_ingest_dropped(const fmd_ingest *g);
+/* The dequeue of demod_thread_fn (src/rtl_fm_player.c:863-876): when at least len bytes are
+ * buffered, copies them to out and returns len, else returns 0.  Not while pump jobs are in flight. */
+uint32_t fmd_ingest_pop(fmd_ingest *g, uint8_t *out, uint32_t len);
 /* Mute the first n bytes of the next callback buffer (retune, :805-810). */
 void fmd_ingest_mute(fmd_ingest *g, int n_bytes);
 /* Demodulate whole blocks that every bound stream has buffered: returns the
  * number of blocks processed per stream (>= 0) or an error.  pcm/lens as in
  * fmd_batch_run_host, for max_blocks blocks. */
 int fmd_batch_pump(fmd_batch *b, int max_blocks, int16_t *pcm, int32_t *lens);
-/* Pipelined form of the same: _begin stages what is buffered (ring -> pinned memory),
- * queues H2D, kernel and D2H and returns the job's block count at once (0: nothing
+/* Pipelined form of the same: _begin queues the H2D of what is buffered (straight from the
+ * pinned rings), the kernel and the D2H, and returns the job's block count at once (0: nothing
  * buffered); _end waits for the oldest job begun and hands out its PCM and lengths.
- * Two jobs may be in flight, so staging and H2D of one overlap the kernel of the other
- * (the demod thread's copy / demodulate alternation, src/rtl_fm_player.c:871-889,
- * without the serialisation). */
+ * Two jobs may be in flight, so the H2D of one overlaps the kernel of the other (the demod
+ * thread's copy / demodulate alternation, src/rtl_fm_player.c:871-889, without the
+ * serialisation).  A job's bytes stay in the ring until their H2D has finished: size the ring
+ * (fmd_ingest_create's ring_bytes) at twice the job when the producer must not wait. */
 int fmd_batch_pump_begin(fmd_batch *b, int max_blocks);
 int fmd_batch_pump_end(fmd_batch *b, int16_t *pcm, int32_t *lens);
 

@@ -97,7 +97,8 @@ _EXPORTS = [
     "fmd_batch_sync", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
-    "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_batch_pump",
+    "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_ingest_set_overflow", "fmd_ingest_pop",
+    "fmd_batch_pump",
     "fmd_batch_pump_begin", "fmd_batch_pump_end",
     "fmd_wav_header", "fmd_wav_open", "fmd_wav_write", "fmd_wav_close",
 ]
@@ -156,6 +157,9 @@ def lib():
     L.fmd_ingest_dropped.restype = C.c_uint64
     L.fmd_ingest_mute.argtypes = [vp, C.c_int]
     L.fmd_ingest_mute.restype = None
+    L.fmd_ingest_set_overflow.argtypes = [vp, C.c_int]
+    L.fmd_ingest_pop.argtypes = [vp, vp, C.c_uint32]
+    L.fmd_ingest_pop.restype = C.c_uint32
     L.fmd_batch_pump.argtypes = [vp, C.c_int, vp, vp]
     L.fmd_batch_pump_begin.argtypes = [vp, C.c_int]
     L.fmd_batch_pump_end.argtypes = [vp, vp, vp]

@@ -160,6 +160,9 @@ struct fmd_batch {
   void *d_state[2];            /* fmd_stream_state[n_streams], ping-pong: a multi-chunk launch
                                   reads one and writes the other                        */
   int cur;                     /* index of the buffer holding the current state          */
+  hipStream_t last_stream;     /* stream of the most recent launch (b->stream or the caller's)      */
+  int launched;                /* a launch has been queued on last_stream                            */
+  hipEvent_t ev_order;         /* orders the state ping-pong when consecutive launches change stream */
   int n_cus;
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
@@ -168,10 +171,11 @@ struct fmd_batch {
   struct fmd_ingest **ingest;  /* [n_streams], NULL when unbound */
   /* fmd_batch_pump_begin/_end: two jobs in flight, each with its own pinned and device buffers */
   struct pump_slot {
-    uint8_t *h_iq; int16_t *h_pcm; int32_t *h_lens;   /* pinned */
+    int16_t *h_pcm; int32_t *h_lens;                   /* pinned */
     void *d_iq, *d_pcm, *d_lens;
     size_t cap_blocks;
     int n_blocks;                                      /* > 0: job in flight */
+    int ring_held;                                     /* its bytes are still held in the rings (H2D source) */
     hipEvent_t h2d_done, done;
   } pump[2];
   int pump_head, pump_tail;    /* next slot to begin / oldest slot not yet ended */
@@ -279,6 +283,7 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&b->ev0)) != hipSuccess || (e = hipEventCreate(&b->ev1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc(&b->d_state[0], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
       (e = hipMalloc(&b->d_state[1], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
       (e = hipMemset(b->d_state[0], 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
@@ -298,10 +303,28 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   return FMD_OK;
 }
 
+/* Wait for everything this batch has queued: its own stream, the copy stream of the pump and
+ * the stream of the most recent launch when the caller supplied one. */
+static hipError_t batch_quiesce(fmd_batch *b) {
+  hipError_t e = hipSuccess, t;
+  if (b->launched && b->last_stream && b->last_stream != b->stream &&
+      (t = hipStreamSynchronize(b->last_stream)) != hipSuccess) e = t;
+  if (b->copy_stream && (t = hipStreamSynchronize(b->copy_stream)) != hipSuccess) e = t;
+  if (b->stream && (t = hipStreamSynchronize(b->stream)) != hipSuccess) e = t;
+  return e;
+}
+
+static void ingest_detach(struct fmd_ingest *g);
+
 void fmd_batch_destroy(fmd_batch *b) {
   if (!b) return;
   hipSetDevice(b->device);
-  if (b->stream) hipStreamSynchronize(b->stream);
+  batch_quiesce(b);
+  /* rings outlive the batch (their owner destroys them with fmd_ingest_destroy, before or
+   * after this call): detach them so that neither side touches freed memory */
+  if (b->ingest)
+    for (int i = 0; i < b->n_streams; i++)
+      if (b->ingest[i]) ingest_detach(b->ingest[i]);
   if (b->d_state[0]) hipFree(b->d_state[0]);
   if (b->d_state[1]) hipFree(b->d_state[1]);
   if (b->d_iq) hipFree(b->d_iq);
@@ -309,7 +332,6 @@ void fmd_batch_destroy(fmd_batch *b) {
   if (b->d_lens) hipFree(b->d_lens);
   for (int i = 0; i < 2; i++) {
     struct pump_slot *p = &b->pump[i];
-    if (p->h_iq) hipHostFree(p->h_iq);
     if (p->h_pcm) hipHostFree(p->h_pcm);
     if (p->h_lens) hipHostFree(p->h_lens);
     if (p->d_iq) hipFree(p->d_iq);
@@ -321,6 +343,7 @@ void fmd_batch_destroy(fmd_batch *b) {
   if (b->copy_stream) hipStreamDestroy(b->copy_stream);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev_order) hipEventDestroy(b->ev_order);
   if (b->stream) hipStreamDestroy(b->stream);
   free(b->ingest);
   free(b);
@@ -360,13 +383,22 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
     if (want > most) want = most;
     if (want > 1) kp.n_chunks = (int)want;
   }
-  const int nxt = (kp.n_chunks > 1) ? (b->cur ^ 1) : b->cur;
+  /* The state is always ping-ponged (the kernel's in / out pointers never alias).  Launches on one
+   * stream are ordered by the stream; when the stream changes between two launches an event makes
+   * the new stream wait for the previous launch, whose output state this one reads. */
+  if (b->launched && b->last_stream != st) {
+    HIP_TRY(hipEventRecord(b->ev_order, b->last_stream));
+    HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
+  }
+  const int nxt = b->cur ^ 1;
   if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev0, st));
   int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state[b->cur],
                       b->d_state[nxt], dbg, st);
   if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
   if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev1, st));
   b->cur = nxt;
+  b->last_stream = st;
+  b->launched = 1;
   b->timed = !b->no_timing;
   return FMD_OK;
 }
@@ -379,7 +411,7 @@ int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_p
 int fmd_batch_sync(fmd_batch *b) {
   if (!b) return fail(FMD_E_ARG, "NULL batch");
   HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(batch_quiesce(b));
   return FMD_OK;
 }
 
@@ -433,7 +465,7 @@ int fmd_batch_run_host(fmd_batch *b, const uint8_t *iq, int n_blocks, int16_t *p
 int fmd_batch_get_state(fmd_batch *b, int stream, fmd_stream_state *out) {
   if (!b || !out || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(batch_quiesce(b));
   HIP_TRY(hipMemcpy(out, (char *)b->d_state[b->cur] + sizeof(*out) * (size_t)stream, sizeof(*out),
                     hipMemcpyDeviceToHost));
   return FMD_OK;
@@ -442,7 +474,7 @@ int fmd_batch_get_state(fmd_batch *b, int stream, fmd_stream_state *out) {
 int fmd_batch_set_state(fmd_batch *b, int stream, const fmd_stream_state *in) {
   if (!b || !in || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
   HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(batch_quiesce(b));
   HIP_TRY(hipMemcpy((char *)b->d_state[b->cur] + sizeof(*in) * (size_t)stream, in, sizeof(*in),
                     hipMemcpyHostToDevice));
   return FMD_OK;
@@ -451,7 +483,7 @@ int fmd_batch_set_state(fmd_batch *b, int stream, const fmd_stream_state *in) {
 int fmd_batch_reset(fmd_batch *b) {
   if (!b) return fail(FMD_E_ARG, "NULL batch");
   HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(batch_quiesce(b));
   HIP_TRY(hipMemset(b->d_state[b->cur], 0, sizeof(fmd_stream_state) * (size_t)b->n_streams));
   return FMD_OK;
 }
@@ -489,6 +521,12 @@ static struct drop_in *drop_find(struct demod_state *d, int create) {
   pthread_mutex_unlock(&g_drop_m);
   return hit;
 }
+
+/* FMD_MATH_FAST in the environment selects the +-1 LSB kernels for the reference-shaped calls;
+ * read once (the first full_demod), not per block. */
+static int g_dropin_math = -1;
+static pthread_once_t g_dropin_once = PTHREAD_ONCE_INIT;
+static void dropin_read_env(void) { g_dropin_math = getenv("FMD_MATH_FAST") ? FMD_MATH_FAST : FMD_MATH_EXACT; }
 
 static void die(const char *what) {
   fprintf(stderr, "fmdemod_mi355x: %s: %s\n", what, fmd_last_error());
@@ -590,7 +628,8 @@ void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 
   struct drop_in *di = drop_find(d, 1);
   if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("full_demod"); }
   if (!d->lpr.br || !d->lpr.fm) { fail(FMD_E_STATE, "init_lp_real_f32 was not called"); die("full_demod"); }
-  const int math = getenv("FMD_MATH_FAST") ? FMD_MATH_FAST : FMD_MATH_EXACT;
+  pthread_once(&g_dropin_once, dropin_read_env);
+  const int math = g_dropin_math;
   fmd_config c = {d->rate_in, d->rate_out, d->rate_out2, d->lpr.mode, d->lpr.size, d->deemph != 0.0,
                   di->convert_mode, d->deemph_lambda, d->volume, (int32_t)d->buf_len, math};
   if (!di->batch || memcmp(&c, &di->cfg, sizeof(c)) != 0) {
@@ -652,61 +691,148 @@ void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 
 }
 
 /* ---- ingest ---------------------------------------------------------------- */
-
+/*
+ * One pinned ring per stream, written by fmd_ingest_callback (any thread: librtlsdr's USB event
+ * thread in the reference, src/rtl_fm_player.c:839-853) and drained by the pump (the demod thread's
+ * role, :855-933).  The ring IS the H2D source: a job's bytes are copied to the device straight from
+ * the ring (no second host copy) and stay accounted as buffered until that copy has finished.
+ *
+ * Accounting (all under g->m):
+ *   rpos      oldest byte not yet released        size      bytes in [rpos, rpos + size) (mod cap)
+ *   inflight  leading bytes of that range handed to jobs whose H2D may still be reading them
+ *   wpos      next write position
+ * Two overflow behaviours (fmd_ingest_set_overflow):
+ *   FMD_OVERFLOW_DROP_OLDEST (default)  the copy wraps at the end of the ring; bytes beyond the capacity
+ *       push rpos forward (the oldest data is lost, counted in `dropped`).  A clean loss.
+ *   FMD_OVERFLOW_REFERENCE  rtlsdr_callback to the letter (:813-834): a transfer that does not fit
+ *       before the end of the ring restarts at offset 0 (no split copy; whatever lies between wpos and
+ *       the end is left as it is), and on overflow only the byte count is clamped - rpos stays, so the
+ *       reader next sees new data where it expected old.  Kept for identical behaviour
+ *       (tests/test_ring_ref.py holds it against the reference's own callback).
+ */
 struct fmd_ingest {
-  fmd_batch *batch;
+  fmd_batch *batch;       /* NULL once the batch has been destroyed */
   int stream;
   uint8_t *ring;          /* pinned host memory */
-  uint32_t cap, rpos, wpos, size;
+  uint32_t cap, rpos, wpos, size, inflight;
+  uint32_t debt;          /* in-flight bytes an overflow has already released (drop-oldest) */
   uint64_t dropped;
   int mute;
+  int overflow_mode;
+  int unbound;            /* created without a batch: ring in pageable memory */
   pthread_mutex_t m;
 };
 
 int fmd_ingest_create(fmd_ingest **out, fmd_batch *b, int stream, uint32_t ring_bytes) {
-  if (!out || !b || stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
-  if (b->ingest[stream]) return fail(FMD_E_STATE, "stream %d already has an ingest ring", stream);
+  if (!out) return fail(FMD_E_ARG, "bad argument");
+  *out = NULL;
   if (ring_bytes == 0) ring_bytes = 16u * FMD_MAXIMUM_BUF_LENGTH;   /* include/rtl_fm_player.h:65 */
+  fmd_ingest *g;
+  if (!b) {
+    /* unbound ring: plain host memory, no device involved; drained with fmd_ingest_pop */
+    g = (fmd_ingest *)calloc(1, sizeof(*g));
+    if (!g) return fail(FMD_E_NOMEM, "out of host memory");
+    g->ring = (uint8_t *)calloc(ring_bytes, 1);       /* zero like the reference's static _input_buffer */
+    if (!g->ring) { free(g); return fail(FMD_E_NOMEM, "out of host memory"); }
+    g->unbound = 1;
+    g->stream = -1;
+    g->cap = ring_bytes;
+    g->overflow_mode = FMD_OVERFLOW_DROP_OLDEST;
+    pthread_mutex_init(&g->m, NULL);
+    *out = g;
+    return FMD_OK;
+  }
+  if (stream < 0 || stream >= b->n_streams) return fail(FMD_E_ARG, "bad argument");
+  if (b->ingest[stream]) return fail(FMD_E_STATE, "stream %d already has an ingest ring", stream);
   if (ring_bytes < (uint32_t)b->cfg.block_len) return fail(FMD_E_ARG, "ring smaller than one block");
-  fmd_ingest *g = (fmd_ingest *)calloc(1, sizeof(*g));
+  if (hipSetDevice(b->device) != hipSuccess) return fail(FMD_E_HIP, "hipSetDevice(%d) failed", b->device);
+  g = (fmd_ingest *)calloc(1, sizeof(*g));
   if (!g) return fail(FMD_E_NOMEM, "out of host memory");
-  HIP_TRY(hipSetDevice(b->device));
   if (hipHostMalloc((void **)&g->ring, ring_bytes, hipHostMallocDefault) != hipSuccess) {
     free(g);
     return fail(FMD_E_NOMEM, "pinned allocation of %u bytes failed", ring_bytes);
   }
+  memset(g->ring, 0, ring_bytes);                     /* zero like the reference's static _input_buffer */
   g->batch = b;
   g->stream = stream;
   g->cap = ring_bytes;
+  g->overflow_mode = FMD_OVERFLOW_DROP_OLDEST;
   pthread_mutex_init(&g->m, NULL);
   b->ingest[stream] = g;
   *out = g;
   return FMD_OK;
 }
 
+/* the batch is going away (fmd_batch_destroy, after it has waited for every copy out of the ring) */
+static void ingest_detach(struct fmd_ingest *g) {
+  pthread_mutex_lock(&g->m);
+  g->batch = NULL;
+  g->inflight = 0;
+  g->debt = 0;
+  pthread_mutex_unlock(&g->m);
+}
+
 void fmd_ingest_destroy(fmd_ingest *g) {
   if (!g) return;
-  if (g->batch && g->batch->ingest) g->batch->ingest[g->stream] = NULL;
-  hipHostFree(g->ring);
+  fmd_batch *b = g->batch;
+  if (b) {
+    if (g->inflight) {                 /* a job still reads this ring: let it finish first */
+      hipSetDevice(b->device);
+      batch_quiesce(b);
+    }
+    if (b->ingest) b->ingest[g->stream] = NULL;
+  }
+  if (g->unbound) free(g->ring);
+  else hipHostFree(g->ring);
   pthread_mutex_destroy(&g->m);
   free(g);
 }
 
-void fmd_ingest_mute(fmd_ingest *g, int n_bytes) {
-  if (g) g->mute = n_bytes;
+int fmd_ingest_set_overflow(fmd_ingest *g, int mode) {
+  if (!g || (mode != FMD_OVERFLOW_DROP_OLDEST && mode != FMD_OVERFLOW_REFERENCE)) return fail(FMD_E_ARG, "bad argument");
+  pthread_mutex_lock(&g->m);
+  g->overflow_mode = mode;
+  pthread_mutex_unlock(&g->m);
+  return FMD_OK;
 }
 
-/* rtlsdr_read_async_cb_t; follows rtlsdr_callback (src/rtl_fm_player.c:790-837):
- * optional mute fill, copy with wrap, drop-oldest accounting. */
+void fmd_ingest_mute(fmd_ingest *g, int n_bytes) {
+  if (!g) return;
+  pthread_mutex_lock(&g->m);
+  g->mute = n_bytes;
+  pthread_mutex_unlock(&g->m);
+}
+
+/* rtlsdr_read_async_cb_t; the role of rtlsdr_callback (src/rtl_fm_player.c:790-837): optional mute
+ * fill (:805-810), copy into the ring under the lock, overflow accounting.  Never blocks on the GPU. */
 void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx) {
   fmd_ingest *g = (fmd_ingest *)ctx;
   if (!g || !buf || len == 0) return;
+  pthread_mutex_lock(&g->m);
   if (g->mute) {
     uint32_t n = (uint32_t)g->mute < len ? (uint32_t)g->mute : len;
-    memset(buf, 127, n);
+    memset(buf, 127, n);               /* the reference fills the USB buffer itself too (:807-808) */
     g->mute = 0;
   }
-  pthread_mutex_lock(&g->m);
+  if (g->overflow_mode == FMD_OVERFLOW_REFERENCE) {
+    if (len > g->cap) { buf += len - g->cap; g->dropped += len - g->cap; len = g->cap; }   /* cannot happen with USB transfers */
+    if (g->wpos + len <= g->cap) {                                  /* :813-820 */
+      memcpy(g->ring + g->wpos, buf, len);
+      g->wpos += len;
+      if (g->wpos == g->cap) g->wpos = 0;
+    } else {                                                        /* :821-827: restart at zero */
+      memcpy(g->ring, buf, len);
+      g->wpos = len;
+    }
+    if ((uint64_t)g->size + len > g->cap) {                         /* :829-834: clamp the count, rpos stays */
+      g->dropped += (uint64_t)g->size + len - g->cap;
+      g->size = g->cap;
+    } else {
+      g->size += len;
+    }
+    pthread_mutex_unlock(&g->m);
+    return;
+  }
   if (len > g->cap) {            /* keep the newest cap bytes */
     g->dropped += len - g->cap;
     buf += len - g->cap;
@@ -717,18 +843,62 @@ void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx) {
   memcpy(g->ring + g->wpos, buf, first);
   memcpy(g->ring, buf + first, len - first);
   g->wpos = (g->wpos + len) % g->cap;
-  g->size += len;
-  if (g->size > g->cap) {        /* overwrote the oldest data */
-    uint32_t over = g->size - g->cap;
+  if ((uint64_t)g->size + len > g->cap) {        /* overwrote the oldest data */
+    const uint32_t over = (uint32_t)((uint64_t)g->size + len - g->cap);
     g->dropped += over;
     g->rpos = (g->rpos + over) % g->cap;
     g->size = g->cap;
+    /* bytes a job was still reading have been overwritten (that job's block is damaged, as any
+     * overflow damages the stream): they are released here, not again when the job ends */
+    const uint32_t eaten = over < g->inflight ? over : g->inflight;
+    g->inflight -= eaten;
+    g->debt += eaten;
+  } else {
+    g->size += len;
   }
   pthread_mutex_unlock(&g->m);
 }
 
-uint32_t fmd_ingest_buffered(const fmd_ingest *g) { return g ? g->size : 0; }
-uint64_t fmd_ingest_dropped(const fmd_ingest *g) { return g ? g->dropped : 0; }
+/* The dequeue of demod_thread_fn (src/rtl_fm_player.c:863-876) for callers that drain a ring
+ * themselves: when at least len bytes are buffered, copies them out and returns len, else 0. */
+uint32_t fmd_ingest_pop(fmd_ingest *g, uint8_t *out, uint32_t len) {
+  if (!g || !out || len == 0 || len > g->cap) return 0;
+  pthread_mutex_lock(&g->m);
+  if (g->size - g->inflight < len) { pthread_mutex_unlock(&g->m); return 0; }
+  const uint32_t from = (g->rpos + g->inflight) % g->cap;
+  uint32_t first = g->cap - from;
+  if (first > len) first = len;
+  memcpy(out, g->ring + from, first);
+  memcpy(out + first, g->ring, len - first);
+  if (g->inflight == 0) {
+    g->rpos = (g->rpos + len) % g->cap;
+    g->size -= len;
+  } else {
+    /* jobs hold the bytes in front of these: cannot be released out of order */
+    pthread_mutex_unlock(&g->m);
+    return 0;
+  }
+  pthread_mutex_unlock(&g->m);
+  return len;
+}
+
+uint32_t fmd_ingest_buffered(const fmd_ingest *gc) {
+  fmd_ingest *g = (fmd_ingest *)gc;
+  if (!g) return 0;
+  pthread_mutex_lock(&g->m);
+  const uint32_t n = g->size - g->inflight;     /* bytes no job has taken yet */
+  pthread_mutex_unlock(&g->m);
+  return n;
+}
+
+uint64_t fmd_ingest_dropped(const fmd_ingest *gc) {
+  fmd_ingest *g = (fmd_ingest *)gc;
+  if (!g) return 0;
+  pthread_mutex_lock(&g->m);
+  const uint64_t n = g->dropped;
+  pthread_mutex_unlock(&g->m);
+  return n;
+}
 
 static int pump_slot_reserve(fmd_batch *b, struct pump_slot *p, int nb) {
   if (!p->done) {
@@ -736,16 +906,14 @@ static int pump_slot_reserve(fmd_batch *b, struct pump_slot *p, int nb) {
     HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
   }
   if ((size_t)nb <= p->cap_blocks) return FMD_OK;
-  if (p->h_iq) hipHostFree(p->h_iq);
   if (p->h_pcm) hipHostFree(p->h_pcm);
   if (p->h_lens) hipHostFree(p->h_lens);
   if (p->d_iq) hipFree(p->d_iq);
   if (p->d_pcm) hipFree(p->d_pcm);
   if (p->d_lens) hipFree(p->d_lens);
-  p->h_iq = NULL; p->h_pcm = NULL; p->h_lens = NULL; p->d_iq = p->d_pcm = p->d_lens = NULL;
+  p->h_pcm = NULL; p->h_lens = NULL; p->d_iq = p->d_pcm = p->d_lens = NULL;
   p->cap_blocks = 0;
   const size_t slots = (size_t)b->n_streams * (size_t)nb;
-  HIP_TRY(hipHostMalloc((void **)&p->h_iq, slots * (size_t)b->cfg.block_len, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&p->h_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&p->h_lens, slots * sizeof(int32_t), hipHostMallocDefault));
   HIP_TRY(hipMalloc(&p->d_iq, slots * (size_t)b->cfg.block_len));
@@ -755,53 +923,106 @@ static int pump_slot_reserve(fmd_batch *b, struct pump_slot *p, int nb) {
   return FMD_OK;
 }
 
-/* Start one job: whole blocks that every bound stream has buffered (at most max_blocks)
- * are moved from the rings into pinned memory, then H2D (copy stream), kernel and D2H
- * (batch stream) are queued and the call returns.  Up to two jobs may be in flight, so
- * the ring -> pinned copy and the H2D of job k+1 overlap the kernel of job k. */
+/* Hand a job's bytes back to the rings' writers: its H2D copies have finished. */
+static void pump_release_ring(fmd_batch *b, struct pump_slot *p) {
+  if (!p->ring_held) return;
+  const uint32_t take = (uint32_t)p->n_blocks * (uint32_t)b->cfg.block_len;
+  for (int s = 0; s < b->n_streams; s++) {
+    fmd_ingest *g = b->ingest[s];
+    if (!g) continue;
+    pthread_mutex_lock(&g->m);
+    uint32_t r = take;
+    const uint32_t d = g->debt < r ? g->debt : r;    /* part an overflow has released already */
+    g->debt -= d;
+    r -= d;
+    if (r > g->inflight) r = g->inflight;
+    g->rpos = (g->rpos + r) % g->cap;
+    g->size -= r;
+    g->inflight -= r;
+    pthread_mutex_unlock(&g->m);
+  }
+  p->ring_held = 0;
+}
+
+/* Release the ring space of jobs whose H2D has completed, without waiting. */
+static void pump_release_completed(fmd_batch *b) {
+  for (int i = 0; i < 2; i++) {
+    struct pump_slot *p = &b->pump[i];
+    if (p->n_blocks > 0 && p->ring_held && hipEventQuery(p->h2d_done) == hipSuccess) pump_release_ring(b, p);
+  }
+}
+
+/* Start one job: whole blocks that every bound stream has buffered (at most max_blocks) are copied
+ * to the device STRAIGHT FROM THE PINNED RINGS on the copy stream (one or two asynchronous copies
+ * per stream), then kernel and D2H are queued on the batch stream and the call returns.  The bytes
+ * stay accounted in the rings until their copy has finished (released by the next _begin / _end that
+ * finds the copy done), so nothing is lost if a later step of this call fails.  Up to two jobs may be
+ * in flight: the H2D of job k+1 runs beside the kernel of job k. */
 int fmd_batch_pump_begin(fmd_batch *b, int max_blocks) {
   if (!b || max_blocks <= 0) return fail(FMD_E_ARG, "bad argument");
   struct pump_slot *p = &b->pump[b->pump_head];
   if (p->n_blocks > 0) return fail(FMD_E_STATE, "two jobs already in flight: call fmd_batch_pump_end first");
+  HIP_TRY(hipSetDevice(b->device));
+  pump_release_completed(b);
   const uint32_t bl = (uint32_t)b->cfg.block_len;
   int nb = max_blocks;
   for (int s = 0; s < b->n_streams; s++) {
     fmd_ingest *g = b->ingest[s];
     if (!g) return fail(FMD_E_STATE, "stream %d has no ingest ring", s);
     pthread_mutex_lock(&g->m);
-    int have = (int)(g->size / bl);
+    int have = (int)((g->size - g->inflight) / bl);
     pthread_mutex_unlock(&g->m);
     if (have < nb) nb = have;
   }
   if (nb == 0) return 0;
-  HIP_TRY(hipSetDevice(b->device));
   if (!b->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-  int rc = pump_slot_reserve(b, p, nb);
+  int rc = pump_slot_reserve(b, p, nb);              /* every buffer the job needs, before a byte is taken */
   if (rc) return rc;
-  for (int s = 0; s < b->n_streams; s++) {
+  const uint32_t take = (uint32_t)nb * bl;
+  int taken = 0;
+  hipError_t e = hipSuccess;
+  for (int s = 0; s < b->n_streams && e == hipSuccess; s++) {
     fmd_ingest *g = b->ingest[s];
-    uint8_t *dst = p->h_iq + (size_t)s * (size_t)nb * bl;
-    const uint32_t take = (uint32_t)nb * bl;
+    uint8_t *dst = (uint8_t *)p->d_iq + (size_t)s * take;
     pthread_mutex_lock(&g->m);
-    uint32_t first = g->cap - g->rpos;
-    if (first > take) first = take;
-    memcpy(dst, g->ring + g->rpos, first);
-    memcpy(dst + first, g->ring, take - first);
-    g->rpos = (g->rpos + take) % g->cap;
-    g->size -= take;
+    const uint32_t from = (g->rpos + g->inflight) % g->cap;
+    g->inflight += take;
     pthread_mutex_unlock(&g->m);
+    taken = s + 1;
+    uint32_t first = g->cap - from;
+    if (first > take) first = take;
+    e = hipMemcpyAsync(dst, g->ring + from, first, hipMemcpyHostToDevice, b->copy_stream);
+    if (e == hipSuccess && take > first)
+      e = hipMemcpyAsync(dst + first, g->ring, take - first, hipMemcpyHostToDevice, b->copy_stream);
   }
   const size_t slots = (size_t)b->n_streams * (size_t)nb;
-  HIP_TRY(hipMemcpyAsync(p->d_iq, p->h_iq, slots * bl, hipMemcpyHostToDevice, b->copy_stream));
-  HIP_TRY(hipEventRecord(p->h2d_done, b->copy_stream));
-  HIP_TRY(hipStreamWaitEvent(b->stream, p->h2d_done, 0));
-  rc = fmd_batch_run_device(b, p->d_iq, nb, p->d_pcm, p->d_lens, NULL);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(p->h_pcm, p->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipMemcpyDeviceToHost,
-                         b->stream));
-  HIP_TRY(hipMemcpyAsync(p->h_lens, p->d_lens, slots * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipEventRecord(p->done, b->stream));
+  if (e == hipSuccess) e = hipEventRecord(p->h2d_done, b->copy_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(b->stream, p->h2d_done, 0);
+  if (e == hipSuccess) {
+    rc = fmd_batch_run_device(b, p->d_iq, nb, p->d_pcm, p->d_lens, NULL);
+    if (rc == FMD_OK) {
+      e = hipMemcpyAsync(p->h_pcm, p->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipMemcpyDeviceToHost,
+                         b->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(p->h_lens, p->d_lens, slots * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream);
+      if (e == hipSuccess) e = hipEventRecord(p->done, b->stream);
+    }
+  }
+  if (e != hipSuccess || rc != FMD_OK) {
+    /* give the bytes back: wait for the copies already queued, then un-take them (they are still in
+     * the rings, so the next call sees them again) */
+    hipStreamSynchronize(b->copy_stream);
+    for (int s = 0; s < taken; s++) {
+      fmd_ingest *g = b->ingest[s];
+      pthread_mutex_lock(&g->m);
+      g->inflight -= take < g->inflight ? take : g->inflight;
+      pthread_mutex_unlock(&g->m);
+    }
+    if (e != hipSuccess) return fail(FMD_E_HIP, "pump: %s (%d)", hipGetErrorString(e), (int)e);
+    return rc;
+  }
   p->n_blocks = nb;
+  p->ring_held = 1;
   b->pump_head ^= 1;
   return nb;
 }
@@ -814,6 +1035,8 @@ int fmd_batch_pump_end(fmd_batch *b, int16_t *pcm, int32_t *lens) {
   if (p->n_blocks <= 0) return 0;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipEventSynchronize(p->done));
+  pump_release_ring(b, p);                           /* done implies its H2D is done */
+  pump_release_completed(b);
   const size_t slots = (size_t)b->n_streams * (size_t)p->n_blocks;
   memcpy(pcm, p->h_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t));
   memcpy(lens, p->h_lens, slots * sizeof(int32_t));
