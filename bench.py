@@ -184,7 +184,9 @@ def e2e_h2d(R, torch, cfg, iq_dev, n_streams, n_blocks, n_jobs, device):
     rings = []
     for s in range(n_streams):
         h = C.c_void_p()
-        rc = L.fmd_ingest_create(C.byref(h), b._h, s, 0)
+        # ring = two jobs: a job's bytes stay in the ring until their H2D is done (zero-copy pump), the
+        # producers meanwhile fill the other half
+        rc = L.fmd_ingest_create(C.byref(h), b._h, s, 2 * n_blocks * BLOCK_LEN)
         if rc:
             raise RuntimeError("fmd_ingest_create: %d" % rc)
         rings.append(h)
@@ -222,8 +224,9 @@ def e2e_h2d(R, torch, cfg, iq_dev, n_streams, n_blocks, n_jobs, device):
         "pcie_gbs": round(nbytes / dt / 1e9, 2),
         "streams": n_streams, "blocks_per_job": n_blocks, "jobs": n_jobs, "feeder_threads": n_thr,
         "ms_per_job": round(dt / n_jobs * 1e3, 3),
-        "path": "host IQ -> fmd_ingest_callback (262144-byte transfers, %d host threads) -> pinned rings -> "
-                "fmd_batch_pump_begin/_end, two jobs in flight -> PCM in host memory; wall clock" % n_thr,
+        "path": "host IQ -> fmd_ingest_callback (262144-byte transfers, %d host threads) -> pinned rings (2 jobs "
+                "deep) -> H2D straight from the rings, fmd_batch_pump_begin/_end with two jobs in flight -> PCM in "
+                "host memory; wall clock" % n_thr,
     }
     for h in rings:
         L.fmd_ingest_destroy(h)

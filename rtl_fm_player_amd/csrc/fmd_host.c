@@ -226,6 +226,20 @@ static void fill_params(fmd_batch *b) {
     for (int j = 0; j < 16; j++) { k->lam_pow[j] = lp; lp *= c->deemph_lambda; }
   }
   k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */
+  {
+    /* carrier_fast: an error e in (x, y) moves sin 2 atan2 by 2 |e| / r; times |vs|, one tap of the
+     * second-stage low-pass (largest |fm|) and the PCM scale it must stay below a quarter LSB.
+     * |e| ~ 1.5 eps with eps = 2e-7 the rounding difference between the fast and the reference
+     * pilot-filter sums  =>  r < K |vs| is redone exactly, K = 12 eps coef max|fm|. */
+    float gmax = 0.f;
+    for (int i = 0; i < (c->size >> 1); i++) gmax = fmaxf(gmax, fabsf(b->taps.fm[i]));
+    float K = 12.0f * 2e-7f * fabsf(k->coef) * gmax;
+    const char *ek = getenv("FMD_CARRIER_K");           /* tuning / tests: override K (0 = never redo) */
+    if (ek) K = (float)atof(ek);
+    const char *es = getenv("FMD_CARRIER_SCALE");       /* ... or scale the derived K */
+    if (es) K *= (float)atof(es);
+    k->car_inv_k2 = K > 0.f ? 1.0f / (K * K) : 3.0e38f;
+  }
   k->size = c->size;
   k->half = c->size >> 1;
   k->mode = c->mode;

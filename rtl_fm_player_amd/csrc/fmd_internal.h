@@ -28,6 +28,8 @@ typedef struct fmdk_params {
   float fm[128], fp[128], fs[128];
   float swf, cwf, lambda, coef;
   float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
+  float car_inv_k2;         /* fast stereo: 1 / K^2, K = radius of (x, y) per unit |vs| below which the
+                               regenerated 38 kHz carrier is redone exactly (fmd_kernels.inc, carrier_fast) */
   int32_t size, half, mode;
   int32_t slow, fast;     /* rate_out2, rate_out                                 */
   int32_t resample;       /* rate_out2 > 0                                       */

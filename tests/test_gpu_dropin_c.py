@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import subprocess
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -67,10 +68,14 @@ def test_callback_thread_while_main_thread_pumps(R, overflow_mode):
         assert L.fmd_ingest_set_overflow(h, overflow_mode) == 0
         rings.append(h)
 
+    deadline = time.time() + 120
+
     def producer(s):
         for k in range(nb_total):
-            while L.fmd_ingest_buffered(rings[s]) > 11 * BL:                # leave room: this test must not overflow
-                pass
+            # leave room: this test must not overflow.  fmd_ingest_buffered does not count the bytes of the (up
+            # to two) jobs in flight, 2 x per_job blocks, which still occupy the ring: 3 + 1 + 8 <= 16 blocks
+            while L.fmd_ingest_buffered(rings[s]) > 3 * BL and time.time() < deadline:
+                time.sleep(0.0005)
             blk = np.ascontiguousarray(iqs[s][k * BL:(k + 1) * BL])
             L.fmd_ingest_callback(blk.ctypes.data, BL, rings[s])
 
@@ -78,6 +83,7 @@ def test_callback_thread_while_main_thread_pumps(R, overflow_mode):
     [t.start() for t in thr]
     outs, lens_all, done, in_flight = [[] for _ in range(ns)], [[] for _ in range(ns)], 0, []
     while done < nb_total:
+        assert time.time() < deadline, "pump made no progress (%d of %d blocks)" % (done, nb_total)
         n = L.fmd_batch_pump_begin(b._h, per_job) if len(in_flight) < 2 else 0
         assert n >= 0, L.fmd_last_error()
         if n > 0:

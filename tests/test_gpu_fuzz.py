@@ -21,6 +21,12 @@ pytestmark = pytest.mark.gpu
 # (seed, case) of tools/fuzz_parity.py 400 <seed> on which a fast kernel has differed from the oracle by
 # more than 1 LSB at some point of the development
 NAMED = [
+    (1, 336),   # 48 k -> 8 k stereo, 128 taps, 65552-byte blocks: 2 LSB   (round-2 start, commit ff07075)
+    (2, 170),   # 48 k -> 8 k stereo, 64 taps: 2 LSB
+    (2, 361),   # 25 k -> 8 k stereo, 90 taps, no de-emphasis: 2 LSB
+    (3, 380),   # 171 k -> 32 k stereo, 200 taps: 6 LSB
+    (4, 96),    # 48 k -> 8 k stereo, 200 taps, offset tuning: 2 LSB
+    (4, 144),   # 48 k -> 8 k stereo, 90 taps (the 45-pair kernel), 65552-byte blocks: 3 LSB
 ]
 
 
