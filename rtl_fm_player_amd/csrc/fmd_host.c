@@ -225,15 +225,32 @@ static void fill_params(fmd_batch *b) {
     float lp = c->deemph_lambda;
     for (int j = 0; j < 16; j++) { k->lam_pow[j] = lp; lp *= c->deemph_lambda; }
   }
+  if (c->math == FMD_MATH_FAST) {
+    /* per-tile flush of the fast kernels: group size and the scan's powers; with de-emphasis off
+     * every power is zero and the flush passes its input through */
+    const long long tile = fmdk_tile();
+    const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2) / c->rate_out + 1 : tile;   /* frames per tile */
+    const int ch = c->mode == 2 ? 2 : 1;
+    k->flush_g = ((fmax + 3) / 4) * ch <= 64 ? 4 : 8;
+    const int on = c->deemph != 0;
+    k->lam_eff = on ? c->deemph_lambda : 0.f;
+    if (!on) memset(k->lam_pow, 0, sizeof(k->lam_pow));
+    double a = on ? pow((double)c->deemph_lambda, (double)k->flush_g) : 0.0;
+    for (int j = 0; j < 8; j++) { k->lam_scan[j] = (float)a; a *= a; }
+  }
   k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */
   {
     /* carrier_fast: an error e in (x, y) moves sin 2 atan2 by 2 |e| / r; times |vs|, one tap of the
      * second-stage low-pass (largest |fm|) and the PCM scale it must stay below a quarter LSB.
-     * |e| ~ 1.5 eps with eps = 2e-7 the rounding difference between the fast and the reference
-     * pilot-filter sums  =>  r < K |vs| is redone exactly, K = 12 eps coef max|fm|. */
+     * |e| ~ 1.5 eps with eps = 1e-7 the rounding difference between the fast and the reference
+     * pilot-filter sums  =>  r < K |vs| is redone exactly, K = 12 eps coef max|fm|.
+     * Measured (tools/fuzz_parity.py 400 {1,2,3,4}, noise input): with K scaled by 0.2 and below the
+     * 1 600 cases still hold 2-6 differences of 2-3 LSB, from 0.6 up none; this K is 3x that bound.
+     * Noise input pays for it (every ~3rd tile holds such a sample at 300 kHz: 0.64 -> 0.83 ms per launch
+     * of 256 x 16 blocks); an FM signal with a pilot never comes near (r ~ 0.06 against K |vs| ~ 0.002). */
     float gmax = 0.f;
     for (int i = 0; i < (c->size >> 1); i++) gmax = fmaxf(gmax, fabsf(b->taps.fm[i]));
-    float K = 12.0f * 2e-7f * fabsf(k->coef) * gmax;
+    float K = 12.0f * 1e-7f * fabsf(k->coef) * gmax;
     const char *ek = getenv("FMD_CARRIER_K");           /* tuning / tests: override K (0 = never redo) */
     if (ek) K = (float)atof(ek);
     const char *es = getenv("FMD_CARRIER_SCALE");       /* ... or scale the derived K */

@@ -28,6 +28,8 @@ typedef struct fmdk_params {
   float fm[128], fp[128], fs[128];
   float swf, cwf, lambda, coef;
   float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
+  float lam_scan[8];        /* fast kernels' per-tile flush: lambda^(flush_g 2^k), k = 0..7 (zero with de-emphasis off) */
+  float lam_eff;            /* lambda, or 0 with de-emphasis off (the fast flush then passes x through)  */
   float car_inv_k2;         /* fast stereo: 1 / K^2, K = radius of (x, y) per unit |vs| below which the
                                regenerated 38 kHz carrier is redone exactly (fmd_kernels.inc, carrier_fast) */
   int32_t size, half, mode;
@@ -43,6 +45,8 @@ typedef struct fmdk_params {
   int32_t perm4;          /* resampler: four frames are a whole, odd number of samples apart (lane map)   */
   int32_t warm_fast;      /* frames after which a zero de-emphasis state is right to 1e-9 */
   int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
+  int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (4 or 8): the smallest with
+                             ceil(frames per tile / flush_g) x channels <= 64 lanes */
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a

@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu $*"
-PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --preheat 0 --data noise --no-cpu --no-check $*"   # counters serialise launches: few steps
+BENCH="python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-e2e $*"
+PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-check $*"   # counters serialise launches: few steps
 echo "== bench (unprofiled)"; $BENCH | tee $OUT/bench_unprofiled.json
 echo "== kernel trace + stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_traced.json 2>$OUT/trace.log
