@@ -263,6 +263,18 @@ static void fill_params(fmd_batch *b) {
   k->slow = c->rate_out2 > 0 ? c->rate_out2 : 1;
   k->fast = c->rate_out2 > 0 ? c->rate_out : 1;
   k->resample = c->rate_out2 > 0;
+  /* floor(n / slow) for n < 2^29 as mulhi(n, m) >> sh: with l = ceil(log2 slow), p = 29 + l and
+   * m = ceil(2^p / slow) the error term m slow - 2^p is below slow, so n (m slow - 2^p) < 2^p for every
+   * n < 2^29 and the quotient is exact; m < 2^30 + 1 fits 32 bits.  Needs p >= 32, i.e. slow >= 5. */
+  k->emit_magic = 0;
+  k->emit_shift = 0;
+  if (k->resample && k->slow >= 5 && (long long)k->fast * 600 < (1LL << 29)) {   /* numerators: < (frames per tile + 1) fast */
+    int l = 0;
+    while ((1LL << l) < k->slow) l++;
+    const int p = 29 + l;
+    const unsigned long long m = (((unsigned long long)1 << p) + (unsigned long long)k->slow - 1) / (unsigned long long)k->slow;
+    if (p >= 32 && m <= 0xffffffffULL) { k->emit_magic = (uint32_t)m; k->emit_shift = (uint32_t)(p - 32); }
+  }
   k->perm4 = k->resample && (4ll * k->fast) % k->slow == 0 && (((4ll * k->fast) / k->slow) & 1);
   k->deemph = c->deemph != 0;
   k->offset_tuning = c->offset_tuning != 0;

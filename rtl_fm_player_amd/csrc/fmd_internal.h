@@ -45,6 +45,8 @@ typedef struct fmdk_params {
   int32_t perm4;          /* resampler: four frames are a whole, odd number of samples apart (lane map)   */
   int32_t warm_fast;      /* frames after which a zero de-emphasis state is right to 1e-9 */
   int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
+  uint32_t emit_magic, emit_shift;   /* resampler emit index: floor(n / slow) = mulhi(n, magic) >> shift for n < 2^29
+                                        (0: slow too small for a 32-bit magic number, the kernel divides by float estimate) */
   int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (4 or 8): the smallest with
                              ceil(frames per tile / flush_g) x channels <= 64 lanes */
 } fmdk_params;
