@@ -199,6 +199,9 @@ static void fill_params(fmd_batch *b) {
   memcpy(k->fm, b->taps.fm, sizeof(k->fm));
   memcpy(k->fp, b->taps.fp, sizeof(k->fp));
   memcpy(k->fs, b->taps.fs, sizeof(k->fs));
+  for (int j = 0; j < 127; j++) k->fm_sh[j] = b->taps.fm[j + 1];
+  k->mono_2to1 = c->math == FMD_MATH_FAST && c->mode == 1 && c->size == 128 && c->rate_out2 > 0 &&
+                 c->rate_out == 2 * c->rate_out2;
   /* fast path of the /8 low-pass: y = c + sum_j s[j] (fb[min(j,31-j)] / 128) u[j]
    * with the (u - 127.5)/128 conversion folded in; s = j^n rotation signs */
   double ci = 0, cq = 0;
@@ -229,7 +232,8 @@ static void fill_params(fmd_batch *b) {
     /* per-tile flush of the fast kernels: group size and the scan's powers; with de-emphasis off
      * every power is zero and the flush passes its input through */
     const long long tile = fmdk_tile();
-    const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2) / c->rate_out + 1 : tile;   /* frames per tile */
+    /* most frames a tile can hold: floor((acc + tile slow) / fast) with acc <= fast - 1 */
+    const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2 + c->rate_out - 1) / c->rate_out : tile;
     const int ch = c->mode == 2 ? 2 : 1;
     k->flush_g = ((fmax + 3) / 4) * ch <= 64 ? 4 : 8;
     const int on = c->deemph != 0;

@@ -26,6 +26,8 @@ typedef struct fmdk_params {
   float fbs[16];          /* fast path: fb / 128 (exact scaling)                 */
   float c_i, c_q;         /* fast path: constant terms of the folded offset      */
   float fm[128], fp[128], fs[128];
+  float fm_sh[128];       /* fm shifted by one tap (fm_sh[i] = fm[i + 1]): tap pairs that start on an odd tap as
+                             aligned scalar pairs (resample_mono_2to1) */
   float swf, cwf, lambda, coef;
   float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
   float lam_scan[8];        /* fast kernels' per-tile flush: lambda^(flush_g 2^k), k = 0..7 (zero with de-emphasis off) */
@@ -47,6 +49,7 @@ typedef struct fmdk_params {
   int32_t warm_tiles;     /* tiles a chunk > 0 replays before its first tile     */
   uint32_t emit_magic, emit_shift;   /* resampler emit index: floor(n / slow) = mulhi(n, magic) >> shift for n < 2^29
                                         (0: slow too small for a 32-bit magic number, the kernel divides by float estimate) */
+  int32_t mono_2to1;      /* fast mono, 128 taps, rate_out == 2 rate_out2: the four-frames-per-lane resampler */
   int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (4 or 8): the smallest with
                              ceil(frames per tile / flush_g) x channels <= 64 lanes */
 } fmdk_params;
