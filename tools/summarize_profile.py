@@ -9,8 +9,10 @@ import sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", tag)
-dst = os.path.join(root, "profiles")
+# optional: <raw dir> <destination dir> (tools/profile_round.sh summarises on the GPU box into gpurun_out/<tag>/,
+# because the raw rocprofv3 output is too large to travel back)
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "gpurun_out", tag)
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
