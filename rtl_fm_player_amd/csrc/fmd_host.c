@@ -422,7 +422,7 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   kp.n_chunks = 1;
   if (kp.warm_tiles > 0 && !getenv("FMD_NO_TIME_SPLIT")) {
     const char *e_w = getenv("FMD_WORKERS_PER_CU");
-    const int per_cu = e_w ? atoi(e_w) : fmdk_workers_per_cu(b->cfg.math);
+    const int per_cu = e_w ? atoi(e_w) : fmdk_workers_per_cu_mode(b->cfg.math, b->cfg.rate_out2 > 0 ? b->cfg.mode : 0);
     const long long m = kp.block_len >> 4, tile = fmdk_tile();
     const long long tiles = ((m + tile - 1) / tile) * n_blocks;
     long long want = ((long long)per_cu * b->n_cus + b->n_streams - 1) / b->n_streams;

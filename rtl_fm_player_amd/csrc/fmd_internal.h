@@ -64,6 +64,7 @@ int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq,
 int fmdk_warm_tiles(const fmdk_params *p, int math);
 int fmdk_tile(void);
 int fmdk_workers_per_cu(int math);
+int fmdk_workers_per_cu_mode(int math, int mode);   /* the same by lpr.mode (the mono kernels may be budgeted differently) */
 /* Mangled-free kernel name as rocprofv3 prints it (prefix match). */
 const char *fmdk_kernel_name(const fmdk_params *p, int math);
 /* Static LDS bytes of the fused kernel (for DESIGN.md / diagnostics). */
