@@ -235,11 +235,12 @@ static void fill_params(fmd_batch *b) {
     /* most frames a tile can hold: floor((acc + tile slow) / fast) with acc <= fast - 1 */
     const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2 + c->rate_out - 1) / c->rate_out : tile;
     const int ch = c->mode == 2 ? 2 : 1;
-    k->flush_g = ((fmax + 3) / 4) * ch <= 64 ? 4 : 8;
+    k->flush_g = (fmax + 3) / 4 <= 64 / ch ? 4 : 8;     /* lanes: 32 groups per channel (stereo), 64 (mono) */
     const int on = c->deemph != 0;
     k->lam_eff = on ? c->deemph_lambda : 0.f;
     if (!on) memset(k->lam_pow, 0, sizeof(k->lam_pow));
     double a = on ? pow((double)c->deemph_lambda, (double)k->flush_g) : 0.0;
+    k->log2_a = (on && c->deemph_lambda > 0.f) ? (float)((double)k->flush_g * log2((double)c->deemph_lambda)) : -1e30f;
     for (int j = 0; j < 8; j++) { k->lam_scan[j] = (float)a; a *= a; }
   }
   k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */

@@ -32,6 +32,7 @@ typedef struct fmdk_params {
   float lam_pow[16];        /* lambda^(j+1), j = 0..15: the fast kernels' blocked de-emphasis */
   float lam_scan[8];        /* fast kernels' per-tile flush: lambda^(flush_g 2^k), k = 0..7 (zero with de-emphasis off) */
   float lam_eff;            /* lambda, or 0 with de-emphasis off (the fast flush then passes x through)  */
+  float log2_a;             /* log2(lambda^flush_g), -1e30 with de-emphasis off: a^(i+1) = exp2((i+1) log2_a) */
   float car_inv_k2;         /* fast stereo: 1 / K^2, K = radius of (x, y) per unit |vs| below which the
                                regenerated 38 kHz carrier is redone exactly (fmd_kernels.inc, carrier_fast) */
   int32_t size, half, mode;
