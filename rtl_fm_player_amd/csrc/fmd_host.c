@@ -280,6 +280,16 @@ static void fill_params(fmd_batch *b) {
     const unsigned long long m = (((unsigned long long)1 << p) + (unsigned long long)k->slow - 1) / (unsigned long long)k->slow;
     if (p >= 32 && m <= 0xffffffffULL) { k->emit_magic = (uint32_t)m; k->emit_shift = (uint32_t)(p - 32); }
   }
+  /* the same for the frames of a tile, floor((acc + tile slow) / fast): numerators below 2^30, p = 30 + l */
+  k->tf_magic = 0;
+  k->tf_shift = 0;
+  if (k->resample && k->fast >= 5 && (long long)k->fast + (long long)fmdk_tile() * k->slow < (1LL << 30)) {
+    int l = 0;
+    while ((1LL << l) < k->fast) l++;
+    const int p = 30 + l;
+    const unsigned long long m = (((unsigned long long)1 << p) + (unsigned long long)k->fast - 1) / (unsigned long long)k->fast;
+    if (p >= 32 && m <= 0xffffffffULL) { k->tf_magic = (uint32_t)m; k->tf_shift = (uint32_t)(p - 32); }
+  }
   k->perm4 = k->resample && (4ll * k->fast) % k->slow == 0 && (((4ll * k->fast) / k->slow) & 1);
   k->deemph = c->deemph != 0;
   k->offset_tuning = c->offset_tuning != 0;
