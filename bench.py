@@ -408,14 +408,15 @@ def main():
     def step():
         batch.run_device(iq, B, pcm, lens, hip_stream=stream.cuda_stream)
 
-    # ---- parity gate (stream 0 and one other stream against the oracle) ----
+    # ---- parity gate (eight streams spread over the batch against the oracle) ----
     parity = None
     if not args.no_check:
         from oracle import OracleStream
         step()
         torch.cuda.synchronize(dev)
         worst = 0
-        for s in sorted({0, (7 * rank + S // 3) % S}):
+        picks = sorted({0, (7 * rank + S // 3) % S} | {(k * S) // 7 for k in range(1, 7)} | {S - 1})
+        for s in picks:
             want, wl = OracleStream(**cfg_kw).run(iq[s].cpu().numpy().reshape(-1), BLOCK_LEN)
             l = lens[s].cpu().numpy()
             assert np.array_equal(l, wl), "result_len mismatch on stream %d" % s
@@ -424,7 +425,7 @@ def main():
             worst = max(worst, int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()))
         tol = 0 if args.math == "exact" else 1
         assert worst <= tol, "PCM differs from the CPU oracle by %d LSB (tolerance %d)" % (worst, tol)
-        parity = {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": 2}
+        parity = {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": len(picks)}
         batch.reset()
 
     batch.set_timing(False)                                  # no per-launch event pair inside the library
