@@ -293,13 +293,17 @@ static void fill_params(fmd_batch *b) {
   k->perm4 = k->resample && (4ll * k->fast) % k->slow == 0 && (((4ll * k->fast) / k->slow) & 1);
   k->deemph = c->deemph != 0;
   k->offset_tuning = c->offset_tuning != 0;
-  /* restart distance for the de-emphasis recurrence: lambda^warm < 1e-12 */
+  /* Restart distance for the de-emphasis recurrence of the exact kernels.  A restarted trajectory is
+   * within one fp32 ulp of the true one once lambda^n < 1e-7; from there a surviving 1-ulp difference
+   * rounds away with probability ~ (1 - lambda) per step, i.e. survives k more steps with lambda^k.
+   * lambda^warm < 1e-25 leaves 1e-18 per restart: with the 1.3 million restarts of a 256 x 16 block
+   * launch, 1e-12 per launch that a carried state is one ulp off (round 1 used 1e-12: 6e-8 per restart). */
   int warm = 0;
   if (k->deemph) {
     const double lam = fabs((double)c->deemph_lambda);
     if (lam <= 0.0) warm = 1;
     else if (lam >= 1.0) warm = 1 << 30;   /* not contracting: never restart */
-    else warm = (int)ceil(log(1e-12) / log(lam));
+    else warm = (int)ceil(log(1e-25) / log(lam));
     if (warm < 16) warm = 16;
     if (warm < (1 << 29)) warm = (warm + 15) & ~15;   /* the kernel restarts in whole 16-frame blocks */
   }

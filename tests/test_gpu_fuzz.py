@@ -85,3 +85,33 @@ def test_bench_parity_gate_for_all_eight_rank_seeds(R, mode):
             d = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
             assert d <= 1, "mode %s rank %d stream %d: |diff| %d" % (mode, rank, s, d)
         del iq
+
+
+def test_bench_line_contract(R):
+    """`python bench.py` (N = 1, a small batch so that it runs in seconds): ONE JSON line with the fields
+    the driver reads, a live roofline (HIP events on the launch stream), the CPU baseline and the
+    H2D-inclusive leg."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--preheat", "4", "--streams", "32", "--blocks", "4", "--cpu-seconds", "1.5",
+                        "--e2e-streams", "8", "--e2e-jobs", "3"], capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank", "parity", "e2e_h2d"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 50
+    assert abs(d["value"] - 32 * 4 * 131072 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 10
+    assert set(cb["configs_single_thread"]) == {"mono_2.4Msps", "stereo_2.4Msps", "nfm_200ksps"}
+    assert d["parity"]["max_abs_lsb"] <= 1 and d["e2e_h2d"]["value"] > 100 and d["e2e_h2d"]["pcie_gbs"] > 0.2
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["kernel_ns"] > 0
