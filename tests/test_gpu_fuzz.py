@@ -27,6 +27,8 @@ NAMED = [
     (3, 380),   # 171 k -> 32 k stereo, 200 taps: 6 LSB
     (4, 96),    # 48 k -> 8 k stereo, 200 taps, offset tuning: 2 LSB
     (4, 144),   # 48 k -> 8 k stereo, 90 taps (the 45-pair kernel), 65552-byte blocks: 3 LSB
+    (15, 95),   # 48 k -> 8 k stereo, 64 taps: 2 LSB with the rate-independent K (found by the seeds 5..24 soak)
+    (20, 249),  # 48 k -> 8 k stereo, 32 taps, 5 streams x 12 blocks in 3 launches: 2 LSB, needed 4 x that K
 ]
 
 
