@@ -97,11 +97,14 @@ def test_callback_and_pop_from_two_threads():
     src = np.random.default_rng(7).integers(0, 256, total, dtype=np.uint8)
     got = []
 
+    import time
+    deadline = time.time() + 120
+
     def producer():
         pos = 0
-        while pos < total:
+        while pos < total and time.time() < deadline:
             n = min(BL // 4, total - pos)
-            while L.fmd_ingest_buffered(h) + n > RING:
+            while L.fmd_ingest_buffered(h) + n > RING and time.time() < deadline:
                 pass                                                      # this test is about ordering, not overflow
             L.fmd_ingest_callback(src[pos:pos + n].ctypes.data, n, h)
             pos += n
@@ -111,6 +114,7 @@ def test_callback_and_pop_from_two_threads():
     out = np.empty(BL // 4, np.uint8)
     n_got = 0
     while n_got < total:
+        assert time.time() < deadline, "ring made no progress"
         if L.fmd_ingest_pop(h, out.ctypes.data, out.size):
             got.append(out.copy())
             n_got += out.size
