@@ -523,3 +523,47 @@ def test_bench_fm_input(R, mode):
                 left, right = got[4000::2].astype(np.float64), got[4001::2].astype(np.float64)
                 assert left.std() > 200 and right.std() > 200 and np.abs(left - right).std() > 100
 
+
+
+@pytest.mark.parametrize("mode", [2, 1, "nfm"])
+def test_full_size_every_stream_against_the_oracle(R, mode):
+    """BASELINE.json configs[2] at full size with 256 DIFFERENT streams (LCG seeds 30000 + s), 16 blocks each:
+    every stream of the launch is compared with the oracle (threads: the oracle call releases the GIL) -
+    exact kernels bit for bit, fast kernels within 1 LSB.  537 M samples per launch, nothing duplicated."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import OracleStream, lcg_bytes
+    S, B = 256, 16
+    kw = dict(rate_in=25000, rate_out2=12500, mode=1) if mode == "nfm" else dict(rate_in=300000, rate_out2=48000, mode=mode)
+    dev = torch.device("cuda:0")
+    host = np.empty((S, B * BL), dtype=np.uint8)
+
+    def fill(s):
+        host[s] = lcg_bytes(B * BL, 30000 + s)[0]
+
+    with ThreadPoolExecutor(16) as ex:
+        list(ex.map(fill, range(S)))
+    iq = torch.from_numpy(host).to(dev)
+
+    def oracle(s):
+        return OracleStream(**kw).run(host[s], BL)
+
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(oracle, range(S)))
+    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+        b = R.BatchDemod(R.wbfm_config(math=math, **kw), S)
+        pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+        lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        b.run_device(iq, B, pcm, lens)
+        b.sync()
+        p_all, l_all = pcm.cpu().numpy(), lens.cpu().numpy()
+        worst = 0
+        for s in range(S):
+            w, wl = want[s]
+            assert np.array_equal(l_all[s], wl), "stream %d lens" % s
+            got = np.concatenate([p_all[s, k, :wl[k]] for k in range(B)])
+            d = int(np.abs(got.astype(np.int32) - w.astype(np.int32)).max())
+            worst = max(worst, d)
+            assert d <= tol, "math %d stream %d: |diff| %d" % (math, s, d)
+        b.close()
