@@ -236,6 +236,8 @@ static void fill_params(fmd_batch *b) {
     const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2 + c->rate_out - 1) / c->rate_out : tile;
     const int ch = c->mode == 2 ? 2 : 1;
     k->flush_g = (fmax + 3) / 4 <= 64 / ch ? 4 : 8;     /* lanes: 32 groups per channel (stereo), 64 (mono) */
+    if (ch == 1 && (fmax + 1) / 2 <= 64 && !getenv("FMD_NO_FLUSH2"))   /* (tuning: keep groups of four) */
+      k->flush_g = 2;                                     /* mono with few frames per tile: shorter groups, fewer instructions */
     const int on = c->deemph != 0;
     k->lam_eff = on ? c->deemph_lambda : 0.f;
     if (!on) memset(k->lam_pow, 0, sizeof(k->lam_pow));

@@ -52,7 +52,7 @@ typedef struct fmdk_params {
                                         (0: slow too small for a 32-bit magic number, the kernel divides by float estimate) */
   int32_t mono_2to1;      /* fast mono, 128 taps, rate_out == 2 rate_out2: the four-frames-per-lane resampler */
   uint32_t tf_magic, tf_shift;       /* frames of a tile: floor(x / fast) = mulhi(x, magic) >> shift for x < 2^30 (0: divide) */
-  int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (4 or 8): the smallest with
+  int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (2 mono only, 4 or 8): the smallest with
                              ceil(frames per tile / flush_g) x channels <= 64 lanes */
 } fmdk_params;
 
