@@ -164,6 +164,7 @@ struct fmd_batch {
   int launched;                /* a launch has been queued on last_stream                            */
   hipEvent_t ev_order;         /* orders the state ping-pong when consecutive launches change stream */
   int n_cus;
+  void *d_fft;                 /* stage-C FFT tables of the fast stereo kernel (fmdk_params.fft_tab), or NULL */
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
   size_t cap_blocks;
@@ -189,6 +190,55 @@ static int max_result_len(const fmd_config *c) {
   else n = m;
   if (c->mode == 2) n *= 2;
   return (int)n;
+}
+
+/* Stage C of the fast stereo kernel as an overlap-save convolution over N = 640 samples (fmd_fft320.inc): with
+ * z[m] = (x[2m], x[2m+1]), Z = FFT320(z) and H = the 640-point spectrum of the 90-tap filter F[j] = t[min(j, 89 - j)],
+ * the spectrum of the (even, odd) pairs of y = F * x is
+ *   Z'[k] = A[k] Z[k] + B[k] conj(Z[320 - k]),   A = (P - iQ) / 2, B = (P + iQ) / 2,
+ *   P = (H[k] + H[k+320]) / 2 + (i/2) conj(W) (H[k] - H[k+320]),  Q = (W/2) (H[k] - H[k+320]) + (i/2) (H[k] + H[k+320]),
+ * W = exp(-2 pi i k / 640); the 1/320 of the unnormalised inverse is folded in.  Bin k = k1 + 5 (e + 8 g) is held by
+ * lane k1 8 + e in register g.  Everything in double, rounded once. */
+#define FFT_TAB_FLOATS (3 * 8 * 64 * 4 + 64 * 13 * 2)
+static void build_fft_tables(const fmd_taps *t, float *out) {
+  const double PI = 3.14159265358979323846;
+  memset(out, 0, sizeof(float) * FFT_TAB_FLOATS);
+  const float *taps[3] = {t->fm, t->fp, t->fs};
+  static double hr[640], hi[640];
+  for (int f = 0; f < 3; f++) {
+    for (int k = 0; k < 640; k++) {
+      double sr = 0, si = 0;
+      for (int j = 0; j < 90; j++) {
+        const double a = -2.0 * PI * (double)((k * j) % 640) / 640.0, v = (double)taps[f][j < 45 ? j : 89 - j];
+        sr += v * cos(a); si += v * sin(a);
+      }
+      hr[k] = sr; hi[k] = si;
+    }
+    for (int k = 0; k < 320; k++) {
+      const double th = 2.0 * PI * k / 640.0, wr = cos(th), wi = -sin(th);          /* W */
+      const double sr = hr[k] + hr[k + 320], si = hi[k] + hi[k + 320], dr = hr[k] - hr[k + 320], di = hi[k] - hi[k + 320];
+      /* conj(W) D and W D */
+      const double cwdr = wr * dr + wi * di, cwdi = wr * di - wi * dr, wdr = wr * dr - wi * di, wdi = wr * di + wi * dr;
+      const double pr = 0.5 * sr - 0.5 * cwdi, pi_ = 0.5 * si + 0.5 * cwdr;          /* P = S/2 + (i/2) conj(W) D */
+      const double qr = 0.5 * wdr - 0.5 * si, qi = 0.5 * wdi + 0.5 * sr;             /* Q = (W/2) D + (i/2) S   */
+      /* -iQ = (qi, -qr), +iQ = (-qi, qr) */
+      const double ar = (pr + qi) / 640.0, ai = (pi_ - qr) / 640.0, br = (pr - qi) / 640.0, bi = (pi_ + qr) / 640.0;
+      const int k1 = k % 5, k2 = k / 5, e = k2 & 7, g = k2 >> 3;
+      float *o = out + (((f * 8 + g) * 64) + k1 * 8 + e) * 4;
+      o[0] = (float)ar; o[1] = (float)ai; o[2] = (float)br; o[3] = (float)bi;
+    }
+  }
+  float *tw = out + 3 * 8 * 64 * 4;
+  for (int l = 0; l < 64; l++) {
+    for (int k = 0; k < 5; k++) {
+      const double a = -2.0 * PI * (double)((l * k) % 320) / 320.0;
+      tw[(l * 13 + k) * 2] = (float)cos(a); tw[(l * 13 + k) * 2 + 1] = (float)sin(a);
+    }
+    for (int k = 0; k < 8; k++) {
+      const double a = -2.0 * PI * (double)(((l & 7) * k) % 64) / 64.0;
+      tw[(l * 13 + 5 + k) * 2] = (float)cos(a); tw[(l * 13 + 5 + k) * 2 + 1] = (float)sin(a);
+    }
+  }
 }
 
 static void fill_params(fmd_batch *b) {
@@ -365,6 +415,20 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
     fmd_batch_destroy(b);
     return rc;
   }
+  if (fmdk_fft_mpx() && b->cfg.math == FMD_MATH_FAST && b->cfg.mode == 2 && b->cfg.size == 90 && b->cfg.rate_out2 > 0) {
+    float *tab = (float *)malloc(sizeof(float) * FFT_TAB_FLOATS);
+    if (!tab) { fmd_batch_destroy(b); return fail(FMD_E_NOMEM, "out of host memory"); }
+    build_fft_tables(&b->taps, tab);
+    if ((e = hipMalloc(&b->d_fft, sizeof(float) * FFT_TAB_FLOATS)) != hipSuccess ||
+        (e = hipMemcpy(b->d_fft, tab, sizeof(float) * FFT_TAB_FLOATS, hipMemcpyHostToDevice)) != hipSuccess) {
+      free(tab);
+      rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e));
+      fmd_batch_destroy(b);
+      return rc;
+    }
+    free(tab);
+    b->kp.fft_tab = (uint64_t)(uintptr_t)b->d_fft;
+  }
   {
     hipDeviceProp_t prop;
     b->n_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -400,6 +464,7 @@ void fmd_batch_destroy(fmd_batch *b) {
       if (b->ingest[i]) ingest_detach(b->ingest[i]);
   if (b->d_state[0]) hipFree(b->d_state[0]);
   if (b->d_state[1]) hipFree(b->d_state[1]);
+  if (b->d_fft) hipFree(b->d_fft);
   if (b->d_iq) hipFree(b->d_iq);
   if (b->d_pcm) hipFree(b->d_pcm);
   if (b->d_lens) hipFree(b->d_lens);
