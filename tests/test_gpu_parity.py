@@ -422,6 +422,25 @@ def test_chunking_does_not_change_results(R, lcg40, monkeypatch):
     assert states[0] == states[1] == states[2]
 
 
+@pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
+def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, monkeypatch, name):
+    """Fast kernels, whole tiles (the own-words decimator hands partial sums from lane to lane and from tile to tile):
+    one worker for the whole launch, many short time chunks and the default split all stay within 1 LSB of the oracle,
+    and the block lengths are the oracle's."""
+    nb = 16
+    want, wlens, _ = oracle_run(CONFIGS[name], lcg40[: nb * BL])
+    for env in ({"FMD_NO_TIME_SPLIT": "1"}, {"FMD_WORKERS_PER_CU": "3"}, {"FMD_WORKERS_PER_CU": "24"}, {}):
+        for k in ("FMD_NO_TIME_SPLIT", "FMD_WORKERS_PER_CU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, lens, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, R.MATH_FAST)
+        b.close()
+        assert np.array_equal(lens[0], wlens), env
+        diff = int(np.abs(got[0].astype(np.int32) - want.astype(np.int32)).max())
+        assert diff <= 1, "%s %s: fast PCM differs from the oracle by %d LSB" % (name, env, diff)
+
+
 def test_misaligned_iq_pointer_is_rejected(R):
     import torch
     cfg = R.wbfm_config(math=R.MATH_FAST, **CONFIGS["stereo_300k"])
