@@ -48,7 +48,9 @@ def parse():
                          "(tools/ramp_check.py: 0.76 ms per launch at first, 0.63 ms from then on)")
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
-    ap.add_argument("--math", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-c"], default="fast",
+                    help="fast = the +-1 LSB kernels the library picks (matrix-pipe stage A unless FMD_MFMA=0); "
+                         "fast-valu / fast-mfma / fast-mfma-c name a kernel family (A/B runs)")
     ap.add_argument("--mode", choices=["stereo", "mono", "nfm"], default="stereo",
                     help="stereo/mono: 2.4 Msps WBFM (rate_in 300k -> 48k); nfm: 200 ksps (25k -> 12.5k mono)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -297,7 +299,10 @@ def measured_traffic(config):
             t = json.load(open(f)).get("hbm_traffic")
         except (OSError, ValueError):
             continue
-        if t and t.get("workload") == config:
+        w = t.get("workload") if t else None
+        # same workload text and the same kernel family (profiles of earlier rounds carry only "math")
+        if w and w.get("workload") == config.get("workload") and \
+                w.get("kernel_family", {"fast": "fast-valu"}.get(w.get("math"), w.get("math"))) == config.get("kernel_family"):
             best = (int(t["traffic_bytes_per_launch"]), os.path.basename(f))
     return best
 
@@ -387,7 +392,8 @@ def main():
         cfg_kw = dict(rate_in=25000, rate_out2=12500, mode=1)          # BASELINE.json configs[4]
     else:
         cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
-    math = R.MATH_FAST if args.math == "fast" else R.MATH_EXACT
+    math = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
+            "fast-mfma-c": R.MATH_FAST_MFMA_C}[args.math]
     cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math, **cfg_kw)
     S, B = args.streams, args.blocks
     batch = R.BatchDemod(cfg, S, device=local)
@@ -496,6 +502,11 @@ def main():
                 ("%d concurrent 200 ksps narrow-FM mono streams per GPU x %d blocks of %d B u8 IQ "
                  "(rate_in 25k -> 12.5k PCM), IQ resident in HBM" % (S, B, BLOCK_LEN)),
                 "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
+                # what ran: the kernel family FMD_MATH_FAST resolved to, and which stages used the matrix pipe
+                "kernel_family": {R.MATH_EXACT: "exact", R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma",
+                                  R.MATH_FAST_MFMA_C: "fast-mfma-c"}.get(batch.math, str(batch.math)),
+                "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C),
+                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (f32 MPX filters)"}.get(batch.math, "none"),
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
                 "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },

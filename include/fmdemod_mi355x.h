@@ -161,7 +161,14 @@ void fmd_demod_release(struct demod_state *d);
 
 /* arithmetic contract */
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
-#define FMD_MATH_FAST 1   /* fused multiply-add, same summation order: PCM within +-1 LSB */
+#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build (FMD_MATH_FAST_MFMA unless the
+                             environment says FMD_MFMA=0) */
+#define FMD_MATH_FAST_VALU 2   /* +-1 LSB, vector ALU only: fused multiply-adds in the reference's summation order */
+#define FMD_MATH_FAST_MFMA 3   /* +-1 LSB, matrix pipe beside the vector ALU: the /8 decimator as exact int8 products
+                                  of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8) */
+#define FMD_MATH_FAST_MFMA_C 4 /* ... and, for 90-tap stereo, the three MPX filters as banded-Toeplitz products on
+                                  v_mfma_f32_16x16x4_f32 (exact fp32 multiply-adds).  Measured SLOWER than _MFMA on
+                                  MI355X: kept selectable and tested, never the default */
 
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
@@ -175,7 +182,7 @@ typedef struct fmd_config {
   float volume;           /* demod_state.volume                                */
   int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
                           /* multiple of 16, >= 64                             */
-  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST                    */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA)   */
 } fmd_config;
 
 /* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /
@@ -223,6 +230,9 @@ void fmd_batch_destroy(fmd_batch *b);
 /* int16 slots per (stream, block) in the PCM buffer (multiple of 8). */
 int fmd_batch_pcm_stride(const fmd_batch *b);
 int fmd_batch_n_streams(const fmd_batch *b);
+/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU or FMD_MATH_FAST_MFMA (FMD_MATH_FAST in the
+ * configuration resolves to one of the last two at creation). */
+int fmd_batch_math(const fmd_batch *b);
 
 /* fmd_batch_destroy waits for everything the batch has queued (on its own streams and on the
  * caller's stream of the most recent launch, which must therefore still exist) and detaches the

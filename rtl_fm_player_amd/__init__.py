@@ -9,6 +9,10 @@ library has not been built.
 from .capi import (  # noqa: F401
     MATH_EXACT,
     MATH_FAST,
+    FAST_MATHS,
+    MATH_FAST_MFMA,
+    MATH_FAST_MFMA_C,
+    MATH_FAST_VALU,
     BatchDemod,
     DemodState,
     FmdConfig,

@@ -10,7 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("FMD_LIB_PATH") or os.path.join(_HERE, "libfmdemod_mi355x.so")   # override: kernel experiments
 
 MATH_EXACT = 0
-MATH_FAST = 1
+MATH_FAST = 1          # the faster +-1 LSB family of this build (MFMA unless FMD_MFMA=0)
+MATH_FAST_VALU = 2     # +-1 LSB, vector ALU only
+MATH_FAST_MFMA = 3     # +-1 LSB, /8 decimator on the matrix pipe
+MATH_FAST_MFMA_C = 4   # ... and the 90-tap stereo MPX filters (fp32 MFMA): measured slower, kept selectable
+FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C)
 MAXIMUM_BUF_LENGTH = 16 * 16384
 
 
@@ -93,7 +97,7 @@ _EXPORTS = [
     "init_u8_f32_table", "init_lp_f32", "init_lp_real_f32", "deinit_lp_real_f32", "demod_init",
     "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release",
     "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
-    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_run_device", "fmd_batch_run_device_debug",
+    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_batch_run_device", "fmd_batch_run_device_debug",
     "fmd_batch_sync", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
@@ -134,6 +138,7 @@ def lib():
     L.fmd_batch_destroy.restype = None
     L.fmd_batch_pcm_stride.argtypes = [vp]
     L.fmd_batch_n_streams.argtypes = [vp]
+    L.fmd_batch_math.argtypes = [vp]
     L.fmd_batch_run_device.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.fmd_batch_run_device_debug.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(FmdDebugTaps)]
     L.fmd_batch_sync.argtypes = [vp]
@@ -223,6 +228,7 @@ class BatchDemod:
                                       self.n_streams, device), "fmd_batch_create")
         self.pcm_stride = lib().fmd_batch_pcm_stride(self._h)
         self.channels = 2 if cfg.mode == 2 else 1
+        self.math = lib().fmd_batch_math(self._h)      # the kernel family MATH_FAST resolved to
 
     def close(self):
         if getattr(self, "_h", None):

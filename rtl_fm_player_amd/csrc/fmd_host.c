@@ -117,7 +117,8 @@ static int check_config(const fmd_config *c) {
   if (c->mode < 0 || c->mode > 2) return fail(FMD_E_ARG, "lpr.mode must be 0, 1 or 2");
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
-  if (c->math != FMD_MATH_EXACT && c->math != FMD_MATH_FAST) return fail(FMD_E_ARG, "math must be exact or fast");
+  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_C)
+    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_C");
   if (c->rate_out2 > 0) {
     if (c->rate_out <= 0 || c->rate_out > 2000000) return fail(FMD_E_UNSUPPORTED, "rate_out must be 1..2000000");
     if (c->rate_out2 > c->rate_out)
@@ -164,7 +165,6 @@ struct fmd_batch {
   int launched;                /* a launch has been queued on last_stream                            */
   hipEvent_t ev_order;         /* orders the state ping-pong when consecutive launches change stream */
   int n_cus;
-  void *d_fft;                 /* stage-C FFT tables of the fast stereo kernel (fmdk_params.fft_tab), or NULL */
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
   size_t cap_blocks;
@@ -192,53 +192,45 @@ static int max_result_len(const fmd_config *c) {
   return (int)n;
 }
 
-/* Stage C of the fast stereo kernel as an overlap-save convolution over N = 640 samples (fmd_fft320.inc): with
- * z[m] = (x[2m], x[2m+1]), Z = FFT320(z) and H = the 640-point spectrum of the 90-tap filter F[j] = t[min(j, 89 - j)],
- * the spectrum of the (even, odd) pairs of y = F * x is
- *   Z'[k] = A[k] Z[k] + B[k] conj(Z[320 - k]),   A = (P - iQ) / 2, B = (P + iQ) / 2,
- *   P = (H[k] + H[k+320]) / 2 + (i/2) conj(W) (H[k] - H[k+320]),  Q = (W/2) (H[k] - H[k+320]) + (i/2) (H[k] + H[k+320]),
- * W = exp(-2 pi i k / 640); the 1/320 of the unnormalised inverse is folded in.  Bin k = k1 + 5 (e + 8 g) is held by
- * lane k1 8 + e in register g.  Everything in double, rounded once. */
-#define FFT_TAB_FLOATS (3 * 8 * 64 * 4 + 64 * 13 * 2)
-static void build_fft_tables(const fmd_taps *t, float *out) {
-  const double PI = 3.14159265358979323846;
-  memset(out, 0, sizeof(float) * FFT_TAB_FLOATS);
-  const float *taps[3] = {t->fm, t->fp, t->fs};
-  static double hr[640], hi[640];
-  for (int f = 0; f < 3; f++) {
-    for (int k = 0; k < 640; k++) {
-      double sr = 0, si = 0;
-      for (int j = 0; j < 90; j++) {
-        const double a = -2.0 * PI * (double)((k * j) % 640) / 640.0, v = (double)taps[f][j < 45 ? j : 89 - j];
-        sr += v * cos(a); si += v * sin(a);
+/* Stage A on the matrix pipe (FMD_MATH_FAST_MFMA): the A operand of v_mfma_i32_16x16x64_i8.
+ * Output m of the /8 low-pass (src/rtl_fm_player.c:253-411, rotation :206-226 folded in) is
+ *   y_c[m] = sum_{j<32} sgn_c(j) fb[min(j, 31-j)] x[8m - 24 + j][sel_c(j)],   x = (u - 127.5) / 128,
+ * a dot product of the 64 window bytes with a vector that has 32 non-zero entries.  With E = sgn round(fb 2^26)
+ * (|E| < 2^23, three balanced int8 limbs) and s = u - 128 the sum  S = sum E s  is EXACT integer arithmetic and
+ *   y = 2^-33 (S + sum E / 2) = 2^-17 S0 + 2^-25 S1 + 2^-33 S2 + bias.
+ * Tap quantisation moves y by at most 32 x 2^-27 |x| <= 2.4e-7 (rms 2.4e-8): the size of the fp32 rounding of the
+ * reference's own sum, inside the +-1 LSB contract like the fused sums of FMD_MATH_FAST_VALU.
+ * Entry [limb][comp][d] holds the 16 bytes (8 samples x {I, Q}) of taps 8d .. 8d+7. */
+static int build_a_tab(const fmd_taps *t, int offset_tuning, fmdk_params *k) {   /* -1: a tap does not fit three limbs */
+  long long sum[2] = {0, 0};
+  int8_t *tab = (int8_t *)k->a_tab;
+  memset(k->a_tab, 0, sizeof(k->a_tab));
+  for (int j = 0; j < 32; j++) {
+    const double tap = (double)t->fb[j < 16 ? j : 31 - j];
+    const long long T = llround(tap * 67108864.0);        /* 2^26 */
+    const int p = j & 3, d = j >> 3, jj = j & 7;
+    for (int comp = 0; comp < 2; comp++) {
+      int sel = comp, sg = 1;
+      if (!offset_tuning) {                                /* j^p: I = (+I, -Q, -I, +Q), Q = (+Q, +I, -Q, -I) */
+        sel = comp ? ((p & 1) ^ 1) : (p & 1);
+        sg = comp ? ((p == 0 || p == 1) ? 1 : -1) : ((p == 0 || p == 3) ? 1 : -1);
       }
-      hr[k] = sr; hi[k] = si;
-    }
-    for (int k = 0; k < 320; k++) {
-      const double th = 2.0 * PI * k / 640.0, wr = cos(th), wi = -sin(th);          /* W */
-      const double sr = hr[k] + hr[k + 320], si = hi[k] + hi[k + 320], dr = hr[k] - hr[k + 320], di = hi[k] - hi[k + 320];
-      /* conj(W) D and W D */
-      const double cwdr = wr * dr + wi * di, cwdi = wr * di - wi * dr, wdr = wr * dr - wi * di, wdi = wr * di + wi * dr;
-      const double pr = 0.5 * sr - 0.5 * cwdi, pi_ = 0.5 * si + 0.5 * cwdr;          /* P = S/2 + (i/2) conj(W) D */
-      const double qr = 0.5 * wdr - 0.5 * si, qi = 0.5 * wdi + 0.5 * sr;             /* Q = (W/2) D + (i/2) S   */
-      /* -iQ = (qi, -qr), +iQ = (-qi, qr) */
-      const double ar = (pr + qi) / 640.0, ai = (pi_ - qr) / 640.0, br = (pr - qi) / 640.0, bi = (pi_ + qr) / 640.0;
-      const int k1 = k % 5, k2 = k / 5, e = k2 & 7, g = k2 >> 3;
-      float *o = out + (((f * 8 + g) * 64) + k1 * 8 + e) * 4;
-      o[0] = (float)ar; o[1] = (float)ai; o[2] = (float)br; o[3] = (float)bi;
+      long long E = sg * T;
+      sum[comp] += E;
+      int limb[3];
+      for (int i = 2; i >= 0; i--) {                       /* balanced digits, least significant first */
+        long long r = ((E % 256) + 256) % 256;
+        if (r >= 128) r -= 256;
+        limb[i] = (int)r;
+        E = (E - r) / 256;
+      }
+      if (E != 0) return -1;                               /* |tap| >= 0.1245: beyond 2^23 / 2^26 (the reference's largest is 0.1239) */
+      for (int l = 0; l < 3; l++) tab[(((l * 2 + comp) * 4 + d) * 16) + 2 * jj + sel] = (int8_t)limb[l];
     }
   }
-  float *tw = out + 3 * 8 * 64 * 4;
-  for (int l = 0; l < 64; l++) {
-    for (int k = 0; k < 5; k++) {
-      const double a = -2.0 * PI * (double)((l * k) % 320) / 320.0;
-      tw[(l * 13 + k) * 2] = (float)cos(a); tw[(l * 13 + k) * 2 + 1] = (float)sin(a);
-    }
-    for (int k = 0; k < 8; k++) {
-      const double a = -2.0 * PI * (double)(((l & 7) * k) % 64) / 64.0;
-      tw[(l * 13 + 5 + k) * 2] = (float)cos(a); tw[(l * 13 + 5 + k) * 2 + 1] = (float)sin(a);
-    }
-  }
+  k->a_bias_i = (float)ldexp((double)sum[0], -34);
+  k->a_bias_q = (float)ldexp((double)sum[1], -34);
+  return 0;
 }
 
 static void fill_params(fmd_batch *b) {
@@ -250,7 +242,7 @@ static void fill_params(fmd_batch *b) {
   memcpy(k->fp, b->taps.fp, sizeof(k->fp));
   memcpy(k->fs, b->taps.fs, sizeof(k->fs));
   for (int j = 0; j < 127; j++) k->fm_sh[j] = b->taps.fm[j + 1];
-  k->mono_2to1 = c->math == FMD_MATH_FAST && c->mode == 1 && c->size == 128 && c->rate_out2 > 0 &&
+  k->mono_2to1 = c->math != FMD_MATH_EXACT && c->mode == 1 && c->size == 128 && c->rate_out2 > 0 &&
                  c->rate_out == 2 * c->rate_out2;
   /* fast path of the /8 low-pass: y = c + sum_j s[j] (fb[min(j,31-j)] / 128) u[j]
    * with the (u - 127.5)/128 conversion folded in; s = j^n rotation signs */
@@ -278,7 +270,7 @@ static void fill_params(fmd_batch *b) {
     float lp = c->deemph_lambda;
     for (int j = 0; j < 16; j++) { k->lam_pow[j] = lp; lp *= c->deemph_lambda; }
   }
-  if (c->math == FMD_MATH_FAST) {
+  if (c->math != FMD_MATH_EXACT) {
     /* per-tile flush of the fast kernels: group size and the scan's powers; with de-emphasis off
      * every power is zero and the flush passes its input through */
     const long long tile = fmdk_tile();
@@ -396,12 +388,25 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
   if (!b) return fail(FMD_E_NOMEM, "out of host memory");
   b->cfg = *cfg;
+  /* FMD_MATH_FAST = the faster of the two +-1 LSB kernel families: the matrix-pipe one, unless FMD_MFMA=0 */
+  if (b->cfg.math == FMD_MATH_FAST) {
+    const char *e_m = getenv("FMD_MFMA");
+    const int sel = e_m ? atoi(e_m) : 1;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C */
+    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : FMD_MATH_FAST_MFMA;
+  }
   b->n_streams = n_streams;
   b->device = device;
   if (taps) b->taps = *taps;
   else if ((rc = fmd_design_taps(cfg, &b->taps))) { free(b); return rc; }
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
+  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C) {
+    /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
+    if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
+      if (cfg->math != FMD_MATH_FAST) { free(b); return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }
+      b->cfg.math = FMD_MATH_FAST_VALU;
+    }
+  }
 
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -409,25 +414,12 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
       (e = hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc(&b->d_state[0], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
       (e = hipMalloc(&b->d_state[1], sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
-      (e = hipMemset(b->d_state[0], 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess ||
-      (e = hipMemset(b->d_state[1], 0, sizeof(fmd_stream_state) * (size_t)n_streams)) != hipSuccess) {
+      (e = hipMemsetAsync(b->d_state[0], 0, sizeof(fmd_stream_state) * (size_t)n_streams, b->stream)) != hipSuccess ||
+      (e = hipMemsetAsync(b->d_state[1], 0, sizeof(fmd_stream_state) * (size_t)n_streams, b->stream)) != hipSuccess ||
+      (e = hipStreamSynchronize(b->stream)) != hipSuccess) {
     rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e));
     fmd_batch_destroy(b);
     return rc;
-  }
-  if (fmdk_fft_mpx() && b->cfg.math == FMD_MATH_FAST && b->cfg.mode == 2 && b->cfg.size == 90 && b->cfg.rate_out2 > 0) {
-    float *tab = (float *)malloc(sizeof(float) * FFT_TAB_FLOATS);
-    if (!tab) { fmd_batch_destroy(b); return fail(FMD_E_NOMEM, "out of host memory"); }
-    build_fft_tables(&b->taps, tab);
-    if ((e = hipMalloc(&b->d_fft, sizeof(float) * FFT_TAB_FLOATS)) != hipSuccess ||
-        (e = hipMemcpy(b->d_fft, tab, sizeof(float) * FFT_TAB_FLOATS, hipMemcpyHostToDevice)) != hipSuccess) {
-      free(tab);
-      rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e));
-      fmd_batch_destroy(b);
-      return rc;
-    }
-    free(tab);
-    b->kp.fft_tab = (uint64_t)(uintptr_t)b->d_fft;
   }
   {
     hipDeviceProp_t prop;
@@ -464,7 +456,6 @@ void fmd_batch_destroy(fmd_batch *b) {
       if (b->ingest[i]) ingest_detach(b->ingest[i]);
   if (b->d_state[0]) hipFree(b->d_state[0]);
   if (b->d_state[1]) hipFree(b->d_state[1]);
-  if (b->d_fft) hipFree(b->d_fft);
   if (b->d_iq) hipFree(b->d_iq);
   if (b->d_pcm) hipFree(b->d_pcm);
   if (b->d_lens) hipFree(b->d_lens);
@@ -489,6 +480,7 @@ void fmd_batch_destroy(fmd_batch *b) {
 
 int fmd_batch_pcm_stride(const fmd_batch *b) { return b ? b->pcm_stride : FMD_E_ARG; }
 int fmd_batch_n_streams(const fmd_batch *b) { return b ? b->n_streams : FMD_E_ARG; }
+int fmd_batch_math(const fmd_batch *b) { return b ? b->cfg.math : FMD_E_ARG; }
 const char *fmd_batch_kernel_name(const fmd_batch *b) {
   return b ? fmdk_kernel_name(&b->kp, b->cfg.math) : "";
 }
@@ -622,7 +614,10 @@ int fmd_batch_reset(fmd_batch *b) {
   if (!b) return fail(FMD_E_ARG, "NULL batch");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(batch_quiesce(b));
-  HIP_TRY(hipMemset(b->d_state[b->cur], 0, sizeof(fmd_stream_state) * (size_t)b->n_streams));
+  /* on the batch's own stream and waited for: hipMemset on device memory may return before the fill has run, and the
+   * batch's stream (non-blocking) does not order itself behind the null stream */
+  HIP_TRY(hipMemsetAsync(b->d_state[b->cur], 0, sizeof(fmd_stream_state) * (size_t)b->n_streams, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return FMD_OK;
 }
 

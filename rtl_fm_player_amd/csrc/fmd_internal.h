@@ -54,9 +54,13 @@ typedef struct fmdk_params {
   uint32_t tf_magic, tf_shift;       /* frames of a tile: floor(x / fast) = mulhi(x, magic) >> shift for x < 2^30 (0: divide) */
   int32_t flush_g;        /* fast kernels: frames per lane in the per-tile flush (2 mono only, 4 or 8): the smallest with
                              ceil(frames per tile / flush_g) x channels <= 64 lanes */
-  uint64_t fft_tab;       /* fast stereo, 90 taps: device address of the stage-C FFT tables (fmd_host.c, build_fft_tables):
-                             float4 ab[3][8][64] = {A.re, A.im, B.re, B.im} of filter f (fm, fp, fs) for the bin held by lane
-                             and register g (fmd_fft320.inc), then float2 tw[64][13] = the lane's twiddles; 0: direct filters */
+  /* matrix-pipe form of stage A (FMD_MATH_FAST_MFMA, v_mfma_i32_16x16x64_i8): the 32 decimator taps with the j^n
+   * rotation signs as 26-bit fixed point, E = sgn * round(fb * 2^26) = l0 2^16 + l1 2^8 + l2 with balanced int8 limbs.
+   * a_tab[limb][comp][d][4 dwords] = the 16 window bytes (8 IQ samples, I and Q slots) that taps 8d .. 8d+7 occupy in
+   * the sum of component comp (0 = I, 1 = Q): the A operand of lane (row = 2 r + comp, g) for K slice s is entry
+   * d = 4 s + g - r, zero outside 0..3 (fmd_host.c, build_a_tab). */
+  int32_t a_tab[3 * 2 * 4 * 4];
+  float a_bias_i, a_bias_q;          /* 2^-34 * sum of E over the window: the (u - 127.5) offset of the reference's table */
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a
@@ -68,7 +72,6 @@ int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq,
  * de-emphasis recurrence has converged (0: the launch must not be split). */
 int fmdk_warm_tiles(const fmdk_params *p, int math);
 int fmdk_tile(void);
-int fmdk_fft_mpx(void);   /* 1: the fast stereo kernel was built with the FFT form of stage C and needs fmdk_params.fft_tab */
 int fmdk_workers_per_cu(int math);
 int fmdk_workers_per_cu_mode(int math, int mode);   /* the same by lpr.mode (the mono kernels may be budgeted differently) */
 /* Mangled-free kernel name as rocprofv3 prints it (prefix match). */

@@ -18,3 +18,11 @@ def lcg40():
     from oracle import lcg_bytes
     buf, _ = lcg_bytes(40 * 262144, 12345)
     return buf
+
+
+@pytest.fixture(params=["valu", "mfma", "mfma_c"])
+def fast_math(request):
+    """The three +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST
+    resolves to), and stages A + C on the matrix pipe (selectable, measured slower)."""
+    import rtl_fm_player_amd as R
+    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C}[request.param]

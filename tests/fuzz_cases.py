@@ -49,7 +49,7 @@ def run_case(R, c, maths=None):
         return []
     iq = np.concatenate([lcg_bytes(nb * block_len, c["seed0"] + s)[0] for s in range(ns)]).reshape(ns, nb, block_len)
     bad = []
-    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
         if maths is not None and math not in maths:
             continue
         try:

@@ -73,7 +73,7 @@ def R():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(LCG_CONFIGS))
-def test_hip_path_reproduces_reference_vectors(R, name, lcg40):
+def test_hip_path_reproduces_reference_vectors(R, name, lcg40, fast_math):
     from oracle import hash16            # only the hash function (an FNV loop), not the demodulator
     g = vectors()
     cfg = LCG_CONFIGS[name]
@@ -90,7 +90,7 @@ def test_hip_path_reproduces_reference_vectors(R, name, lcg40):
         assert np.array_equal(bits(list(st.bm)[:n]), bits(g[name + "/state_bm"]))
         assert np.array_equal(bits(list(st.bs)[:n]), bits(g[name + "/state_bs"]))
     b.close()
-    pcm, lens, b = _gpu_run(R, cfg, lcg40, 40, R.MATH_FAST)
+    pcm, lens, b = _gpu_run(R, cfg, lcg40, 40, fast_math)
     check_run(name, pcm, lens, hash16, tol=1)
     b.close()
 
@@ -100,7 +100,7 @@ def test_hip_path_reproduces_reference_vectors(R, name, lcg40):
 def test_hip_path_reproduces_reference_vectors_fm_broadcast(R, name):
     from oracle import dds_bytes, hash16
     iq = dds_bytes(10 * BL, fs=2400000)
-    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
         pcm, lens, b = _gpu_run(R, DDS_CONFIGS[name], iq, 10, math)
         check_run(name, pcm, lens, hash16, tol=tol)
         b.close()

@@ -70,9 +70,9 @@ def test_exact_bit_identical_40_blocks(R, lcg40, name):
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_fast_within_one_lsb(R, lcg40, name):
+def test_fast_within_one_lsb(R, lcg40, name, fast_math):
     want, wlens, _ = oracle_run(CONFIGS[name], lcg40)
-    got, lens, _ = gpu_run(R, CONFIGS[name], lcg40, 40, R.MATH_FAST)
+    got, lens, _ = gpu_run(R, CONFIGS[name], lcg40, 40, fast_math)
     assert np.array_equal(lens[0], wlens)
     d = np.abs(got[0].astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1, "max |diff| %d at %d" % (d.max(), int(d.argmax()))
@@ -143,7 +143,7 @@ def test_many_streams_independent(R):
 
 @pytest.mark.parametrize("block_len", [64, 80, 1024, 16 * 2048 + 16, 16 * 2048 + 48, 50000 * 16 // 16 * 16])
 @pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
-def test_ragged_block_lengths(R, lcg40, name, block_len):
+def test_ragged_block_lengths(R, lcg40, name, block_len, fast_math):
     """Block lengths that are not tile multiples, down to the 64-byte minimum."""
     nb = 6
     iq = lcg40[: nb * block_len]
@@ -151,19 +151,19 @@ def test_ragged_block_lengths(R, lcg40, name, block_len):
     got, lens, _ = gpu_run(R, CONFIGS[name], iq, nb, R.MATH_EXACT, block_len=block_len)
     assert np.array_equal(lens[0], wlens)
     assert np.array_equal(got[0], want)
-    fast, flens, _ = gpu_run(R, CONFIGS[name], iq, nb, R.MATH_FAST, block_len=block_len)
+    fast, flens, _ = gpu_run(R, CONFIGS[name], iq, nb, fast_math, block_len=block_len)
     assert np.array_equal(flens[0], wlens)
     assert np.abs(fast[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
 @pytest.mark.parametrize("name", ["stereo_300k", "mono_300k"])
-def test_fast_state_carried_across_launches(R, lcg40, name):
+def test_fast_state_carried_across_launches(R, lcg40, name, fast_math):
     """Fast kernels, 12 blocks as 1, 3 and 12 launches: the carried state (including the
     de-emphasis state made by the blocked recurrence) keeps every split within 1 LSB."""
     nb = 12
     want, _, _ = oracle_run(CONFIGS[name], lcg40[: nb * BL])
     for launches in (1, 3, 12):
-        got, _, _ = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, R.MATH_FAST, launches=launches)
+        got, _, _ = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, fast_math, launches=launches)
         assert np.abs(got[0].astype(np.int32) - want.astype(np.int32)).max() <= 1, launches
 
 
@@ -190,7 +190,7 @@ def test_variant_configs(R, lcg40, kw):
     dict(rate_in=300000, rate_out2=48000, mode=2, tau=300e-6),            # lambda = 0.933
     dict(rate_in=300000, rate_out2=96000, mode=2, tau=75e-6),             # lambda = 0.870, 164 frames per tile
 ])
-def test_slow_deemphasis(R, lcg40, kw):
+def test_slow_deemphasis(R, lcg40, kw, fast_math):
     """De-emphasis that decays slowly: the blocked recurrence of the fast kernels (scan over
     16-frame groups) and the chunk warm-up lengths must hold for lambda close to 1."""
     nb = 8
@@ -198,12 +198,12 @@ def test_slow_deemphasis(R, lcg40, kw):
     got, lens, _ = gpu_run(R, kw, lcg40[: nb * BL], nb, R.MATH_EXACT)
     assert np.array_equal(lens[0], wlens)
     assert np.array_equal(got[0], want)
-    fast, flens, _ = gpu_run(R, kw, lcg40[: nb * BL], nb, R.MATH_FAST)
+    fast, flens, _ = gpu_run(R, kw, lcg40[: nb * BL], nb, fast_math)
     assert np.array_equal(flens[0], wlens)
     assert np.abs(fast[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
-def test_synthetic_fm_stereo(R):
+def test_synthetic_fm_stereo(R, fast_math):
     """Integer-DDS stereo multiplex: exact bit-identical, fast within 1 LSB, and audible tones."""
     from oracle import dds_bytes
     nb = 8
@@ -211,7 +211,7 @@ def test_synthetic_fm_stereo(R):
     want, _, _ = oracle_run(CONFIGS["stereo_300k"], iq)
     got, _, _ = gpu_run(R, CONFIGS["stereo_300k"], iq, nb, R.MATH_EXACT)
     assert np.array_equal(got[0], want)
-    fast, _, _ = gpu_run(R, CONFIGS["stereo_300k"], iq, nb, R.MATH_FAST)
+    fast, _, _ = gpu_run(R, CONFIGS["stereo_300k"], iq, nb, fast_math)
     assert np.abs(fast[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
     left = want[0::2].astype(np.float64)
     assert left[4000:].std() > 200          # a demodulated tone, not silence
@@ -387,7 +387,7 @@ def test_full_size_batch_properties(R):
     iq[1::2] = torch.from_numpy(other).to(dev)
     want, wl = OracleStream(**CONFIGS["stereo_300k"]).run(base, BL)
     want_o, wl_o = OracleStream(**CONFIGS["stereo_300k"]).run(other, BL)
-    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
         b = R.BatchDemod(R.wbfm_config(math=math, **CONFIGS["stereo_300k"]), S)
         pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
         lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
@@ -423,7 +423,7 @@ def test_chunking_does_not_change_results(R, lcg40, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
-def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, monkeypatch, name):
+def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, monkeypatch, name, fast_math):
     """Fast kernels, whole tiles (the own-words decimator hands partial sums from lane to lane and from tile to tile):
     one worker for the whole launch, many short time chunks and the default split all stay within 1 LSB of the oracle,
     and the block lengths are the oracle's."""
@@ -434,7 +434,7 @@ def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, monkeypatch, name):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        got, lens, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, R.MATH_FAST)
+        got, lens, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, fast_math)
         b.close()
         assert np.array_equal(lens[0], wlens), env
         diff = int(np.abs(got[0].astype(np.int32) - want.astype(np.int32)).max())
@@ -454,7 +454,7 @@ def test_misaligned_iq_pointer_is_rejected(R):
 
 
 @pytest.mark.parametrize("mode", [2, 1])
-def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode):
+def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode, fast_math):
     """Noise is the worst case for a non-bit-exact discriminator: phase steps land arbitrarily
     close to the +-pi branch cut, where a last-bit difference flips the output by 2 pi.  The fast
     kernels redo such samples in exact arithmetic; seed 99 holds a known crossing (block 4)."""
@@ -466,7 +466,7 @@ def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode):
     seeds = [99] + list(range(5000, 5000 + S - 1))
     host = [lcg_bytes(B * BL, sd)[0] for sd in seeds]
     iq = torch.stack([torch.from_numpy(h) for h in host]).to(dev)
-    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **kw), S)
+    b = R.BatchDemod(R.wbfm_config(math=fast_math, **kw), S)
     pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -482,7 +482,7 @@ def test_fast_math_on_noise_streams_stays_within_one_lsb(R, mode):
 
 
 
-def test_fast_math_nfm_noise_next_to_the_origin(R):
+def test_fast_math_nfm_noise_next_to_the_origin(R, fast_math):
     """NFM on uniform noise (bench.py's generator and seed): stream 0 holds a decimated sample of
     magnitude 1e-4, whose phase a 1e-7 rounding difference moves by 3 LSB of PCM; the fast kernels
     redo samples that close to the origin in exact arithmetic."""
@@ -494,7 +494,7 @@ def test_fast_math_nfm_noise_next_to_the_origin(R):
     g = torch.Generator(device=dev)
     g.manual_seed(12345)
     iq = torch.randint(0, 256, (S, B, BL), dtype=torch.uint8, device=dev, generator=g)
-    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **kw), S)
+    b = R.BatchDemod(R.wbfm_config(math=fast_math, **kw), S)
     pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -525,7 +525,7 @@ def test_bench_fm_input(R, mode):
     dev = torch.device("cuda:0")
     iq = bench.synth_fm_iq(torch, dev, S, B * BL // 2, 200e3 if nfm else 2.4e6, not nfm, 777).view(S, B, BL)
     host = iq.cpu().numpy()
-    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
         b = R.BatchDemod(R.wbfm_config(math=math, **kw), S)
         pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
         lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
@@ -569,7 +569,7 @@ def test_full_size_every_stream_against_the_oracle(R, mode):
 
     with ThreadPoolExecutor(16) as ex:
         want = list(ex.map(oracle, range(S)))
-    for math, tol in ((R.MATH_EXACT, 0), (R.MATH_FAST, 1)):
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
         b = R.BatchDemod(R.wbfm_config(math=math, **kw), S)
         pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
         lens = torch.zeros((S, B), dtype=torch.int32, device=dev)

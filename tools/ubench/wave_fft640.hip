@@ -1,8 +1,8 @@
-// Check and time rtl_fm_player_amd/csrc/fmd_fft320.inc on its own: three 90-tap FIRs on one input as an overlap-save
+// Check and time tools/ubench/fmd_fft320.inc on its own: three 90-tap FIRs on one input as an overlap-save
 // convolution inside ONE wavefront, N = 640 real samples per block (128 of history + 512 new = one tile of the kernel),
 // handled as a 320-point complex FFT of (even, odd) pairs:
 //   Z = FFT320(z),  Z'_f[k] = A_f[k] Z[k] + B_f[k] conj(Z[320 - k]),  z'_f = IFFT320(Z'_f),  y_f[2m] = Re z'_f[m], y_f[2m+1] = Im z'_f[m].
-//   hipcc --offload-arch=gfx950 -O3 -I../../rtl_fm_player_amd/csrc -o wave_fft640 wave_fft640.hip && ./wave_fft640
+//   hipcc --offload-arch=gfx950 -O3 -o wave_fft640 wave_fft640.hip && ./wave_fft640
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <complex>
@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "fmd_fft320.inc"
+#include "fmd_fft320.inc"   /* tools/ubench/ (moved from csrc/ in round 3) */
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
