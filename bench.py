@@ -110,8 +110,14 @@ def _cpu_stream_factory():
     otherwise the bit-exact restatement oracle/fm_oracle.c (kind "port")."""
     try:
         from oracle import refbind
-        if refbind.have_ref():
-            return refbind.RefStream, "reference", "oracle/_ref/libref.so = the reference's rotate_90_u8_f32 + full_demod, gcc -O3"
+        from oracle.build_ref import ref_status
+        st = ref_status()
+        # only the library build_ref made from the PINNED reference lines (oracle/ref_pin.json) and whose bytes on
+        # disk still hash to what it recorded is timed as "the reference"
+        if st and st["pinned"] and refbind.have_ref():
+            return refbind.RefStream, "reference", ("oracle/_ref/libref.so = the reference's rotate_90_u8_f32 + full_demod, "
+                                                    "gcc -O3; reference lines sha256 %s, library sha256 %s"
+                                                    % (st["slices_sha256"][:16], st["so_sha256"][:16]))
     except Exception:                       # noqa: BLE001 - any problem with the optional library: use the port
         pass
     from oracle import OracleStream
@@ -307,33 +313,71 @@ def measured_traffic(config):
     return best
 
 
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd: nodes with SIMDs), without opening a HIP
+    device; None where the topology is not readable (the ranks then find out themselves)."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            return None
+        n += int(props.get("simd_count", "0")) > 0
+    return n
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` with no rank environment: start N fresh ranks of this script.
-    Nothing here imports torch or touches HIP except a device COUNT, which does not initialise
-    the GPU; the children are new processes (subprocess), never an exec of this one."""
+    """`python bench.py --gpus N` with no rank environment: start N fresh ranks of this script and supervise them.
+    The launcher itself never imports torch and never touches HIP (the device count comes from sysfs); the ranks are
+    new processes (subprocess), never an exec of this one.  If a rank exits non-zero the others - who would sit in the
+    rendezvous until its timeout - are terminated and the launcher exits non-zero."""
+    import tempfile
     n = args.gpus
     if not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        have = kfd_gpu_count()
+        if have is not None and have < n:
             raise SystemExit("bench.py: --gpus %d but this node shows %d HIP device(s)" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        print("bench.py: ranks " + " ".join(str(p.pid) for p in procs), file=sys.stderr, flush=True)
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = r
+            time.sleep(0.05)
+        if failed is not None:                      # stop the others: SIGTERM, then SIGKILL after a grace period
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 5.0
+            for p in procs:
+                try:
+                    p.wait(max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        codes = [p.wait() for p in procs]
+        out0.seek(0)
+        text = out0.read().decode()
+    sys.stdout.write(text)
     sys.stdout.flush()
     if any(codes):
-        raise SystemExit("bench.py: rank exit codes %s" % codes)
-    if not any(l.startswith("{") for l in out0.splitlines()):
+        raise SystemExit("bench.py: rank %s failed; rank exit codes %s" % (failed, codes))
+    if not any(l.startswith("{") for l in text.splitlines()):
         raise SystemExit("bench.py: rank 0 printed no JSON line")
 
 
@@ -342,6 +386,8 @@ def dry_run(args, rank, world):
     import torch
     import torch.distributed as dist
     from rtl_fm_player_amd.shard import gather_counters, shard_streams
+    if os.environ.get("FMD_BENCH_DRYRUN_FAIL_RANK") == str(rank):      # tests: a rank that dies before the rendezvous
+        sys.exit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     first, count = shard_streams(args.streams * world, world, rank)

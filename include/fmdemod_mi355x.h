@@ -233,6 +233,10 @@ int fmd_batch_n_streams(const fmd_batch *b);
 /* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU or FMD_MATH_FAST_MFMA (FMD_MATH_FAST in the
  * configuration resolves to one of the last two at creation). */
 int fmd_batch_math(const fmd_batch *b);
+/* How a launch is cut into time chunks (one worker wavefront each; results do not depend on it - the tests hold the
+ * library to that through this call): workers_per_cu > 0 = cut until the grid offers that many workers per CU,
+ * 0 = the kernels' own figure (default), < 0 = never cut (one worker per stream). */
+int fmd_batch_set_time_split(fmd_batch *b, int workers_per_cu);
 
 /* fmd_batch_destroy waits for everything the batch has queued (on its own streams and on the
  * caller's stream of the most recent launch, which must therefore still exist) and detaches the

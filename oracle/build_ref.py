@@ -28,6 +28,7 @@ the GPU box like the product's own built library; /root/reference does not exist
 nothing at run time reads it).  Skipped with a message when /root/reference is absent.
 """
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -123,6 +124,32 @@ def _shim(name):
         return ['#line 1 "%s"' % path] + f.read().split("\n")
 
 
+def load_pin():
+    """oracle/ref_pin.json: sha256 of the reference lines this recipe slices (committed; numbers, not source)."""
+    try:
+        with open(os.path.join(HERE, "ref_pin.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def ref_status():
+    """What oracle/_ref/libref.so is: {"slices_sha256", "so_sha256", "pinned"} where the library on disk is the one
+    build_ref made from the pinned reference lines (its hash is re-checked here), else None."""
+    so = ref_paths()[0]
+    try:
+        with open(os.path.join(OUT, "libref.meta.json")) as f:
+            meta = json.load(f)
+        with open(so, "rb") as f:
+            actual = hashlib.sha256(f.read()).hexdigest()
+    except (OSError, ValueError):
+        return None
+    pin = load_pin()
+    ok = bool(meta.get("pinned")) and pin is not None and pin.get("slices_sha256") == meta.get("slices_sha256") \
+        and actual == meta.get("so_sha256")
+    return dict(meta, pinned=ok, so_sha256_on_disk=actual)
+
+
 def reference_present():
     return os.path.isfile(os.path.join(REF, SRC)) and os.path.isfile(os.path.join(REF, HDR))
 
@@ -154,11 +181,26 @@ def build_ref(force=False, quiet=False):
             if f.read().strip() == stamp:
                 return True
     head = ["#include <%s>" % h for h in LIBC]
-    text = "\n".join(head + _slice(HEADER_RANGES) + _slice(HOT_PATH) + _shim("ref_shim.c")) + "\n"
+    hot = _slice(HEADER_RANGES) + _slice(HOT_PATH)
+    # Pin: the text handed to gcc is untrusted input that becomes a library this process loads.  Its hash (the sliced
+    # reference lines only, without the #line markers that carry the tree's path) must equal the committed one
+    # (oracle/ref_pin.json); a tree that differs is built only on request (FMD_REFERENCE_UNPINNED=1) and marked so,
+    # and bench.py then times the port instead.
+    sliced = hashlib.sha256("\n".join(l for l in hot if not l.startswith("#line ")).encode()).hexdigest()
+    pin = load_pin()
+    pinned = pin is not None and pin.get("slices_sha256") == sliced
+    if not pinned and not os.environ.get("FMD_REFERENCE_UNPINNED"):
+        raise SystemExit("build_ref: the reference lines hash to %s, oracle/ref_pin.json says %s - not building "
+                         "(FMD_REFERENCE_UNPINNED=1 builds an unpinned library)" % (sliced, pin and pin.get("slices_sha256")))
+    text = "\n".join(head + hot + _shim("ref_shim.c")) + "\n"
     _compile(text, so)
     ring_head = head + ['#include "%s"' % os.path.join(REF, "include", "rtl-sdr.h")]
     text = "\n".join(ring_head + _slice(RING_RANGES) + _shim("ref_ring_shim.c")) + "\n"
     _compile(text, ring, extra=["-I" + os.path.join(REF, "include")])   # rtl-sdr.h includes <rtl-sdr_export.h>
+    with open(so, "rb") as f:
+        so_hash = hashlib.sha256(f.read()).hexdigest()
+    with open(os.path.join(OUT, "libref.meta.json"), "w") as f:
+        json.dump({"slices_sha256": sliced, "so_sha256": so_hash, "pinned": pinned}, f)
     with open(stamp_file, "w") as f:
         f.write(stamp + "\n")
     if not quiet:

@@ -97,7 +97,7 @@ _EXPORTS = [
     "init_u8_f32_table", "init_lp_f32", "init_lp_real_f32", "deinit_lp_real_f32", "demod_init",
     "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release",
     "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
-    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_batch_run_device", "fmd_batch_run_device_debug",
+    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_batch_set_time_split", "fmd_batch_run_device", "fmd_batch_run_device_debug",
     "fmd_batch_sync", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
@@ -139,6 +139,7 @@ def lib():
     L.fmd_batch_pcm_stride.argtypes = [vp]
     L.fmd_batch_n_streams.argtypes = [vp]
     L.fmd_batch_math.argtypes = [vp]
+    L.fmd_batch_set_time_split.argtypes = [vp, C.c_int]
     L.fmd_batch_run_device.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.fmd_batch_run_device_debug.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(FmdDebugTaps)]
     L.fmd_batch_sync.argtypes = [vp]
@@ -267,6 +268,10 @@ class BatchDemod:
         pcm, lens = self.run_host(iq, n_blocks)
         out = [np.concatenate([pcm[s, b, :lens[s, b]] for b in range(n_blocks)]) for s in range(self.n_streams)]
         return out, lens
+
+    def set_time_split(self, workers_per_cu):
+        """Time chunks per launch: > 0 workers per CU to cut for, 0 default, < 0 never cut; see fmd_batch_set_time_split."""
+        _check(lib().fmd_batch_set_time_split(self._h, int(workers_per_cu)), "fmd_batch_set_time_split")
 
     def set_timing(self, on):
         """Bracket every launch with an event pair (default) or not; see fmd_batch_set_timing."""

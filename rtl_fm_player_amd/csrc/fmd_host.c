@@ -77,6 +77,18 @@ int fmd_device_count(void) {
   return n;
 }
 
+/* Environment knobs that change the arithmetic thresholds or the kernels' shape exist only in tuning builds
+ * (make EXTRA_CFLAGS=-DFMD_TUNING): the shipped library reads FMD_MFMA (kernel family behind FMD_MATH_FAST) and
+ * FMD_MATH_FAST (drop-in surface) and nothing else. */
+static const char *tuning_env(const char *name) {
+#ifdef FMD_TUNING
+  return getenv(name);
+#else
+  (void)name;
+  return NULL;
+#endif
+}
+
 /* ---- filter design: init_lp_f32 / init_lp_real_f32 restated ------------- */
 
 float fmd_deemph_lambda(int output_rate, double tau) {
@@ -119,6 +131,10 @@ static int check_config(const fmd_config *c) {
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
   if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_C)
     return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_C");
+  /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
+   * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
+  if (c->math != FMD_MATH_EXACT && c->deemph && !(c->deemph_lambda > 0.f && c->deemph_lambda < 1.f))
+    return fail(FMD_E_UNSUPPORTED, "the fast kernels need 0 < deemph_lambda < 1 (got %g): use FMD_MATH_EXACT", (double)c->deemph_lambda);
   if (c->rate_out2 > 0) {
     if (c->rate_out <= 0 || c->rate_out > 2000000) return fail(FMD_E_UNSUPPORTED, "rate_out must be 1..2000000");
     if (c->rate_out2 > c->rate_out)
@@ -165,6 +181,7 @@ struct fmd_batch {
   int launched;                /* a launch has been queued on last_stream                            */
   hipEvent_t ev_order;         /* orders the state ping-pong when consecutive launches change stream */
   int n_cus;
+  int time_split;              /* fmd_batch_set_time_split: 0 default, > 0 workers per CU to cut for, < 0 never split */
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
   size_t cap_blocks;
@@ -177,6 +194,7 @@ struct fmd_batch {
     size_t cap_blocks;
     int n_blocks;                                      /* > 0: job in flight */
     int ring_held;                                     /* its bytes are still held in the rings (H2D source) */
+    int failed;                                        /* hipError_t of a D2H enqueue that failed after the kernel was launched */
     hipEvent_t h2d_done, done;
   } pump[2];
   int pump_head, pump_tail;    /* next slot to begin / oldest slot not yet ended */
@@ -278,7 +296,7 @@ static void fill_params(fmd_batch *b) {
     const long long fmax = c->rate_out2 > 0 ? (tile * c->rate_out2 + c->rate_out - 1) / c->rate_out : tile;
     const int ch = c->mode == 2 ? 2 : 1;
     k->flush_g = (fmax + 3) / 4 <= 64 / ch ? 4 : 8;     /* lanes: 32 groups per channel (stereo), 64 (mono) */
-    if (ch == 1 && (fmax + 1) / 2 <= 64 && !getenv("FMD_NO_FLUSH2"))   /* (tuning: keep groups of four) */
+    if (ch == 1 && (fmax + 1) / 2 <= 64 && !tuning_env("FMD_NO_FLUSH2"))   /* (tuning builds: keep groups of four) */
       k->flush_g = 2;                                     /* mono with few frames per tile: shorter groups, fewer instructions */
     const int on = c->deemph != 0;
     k->lam_eff = on ? c->deemph_lambda : 0.f;
@@ -309,9 +327,9 @@ static void fill_params(fmd_batch *b) {
     if (widen < 1.0) widen = 1.0;
     if (widen > 25.0) widen = 25.0;
     float K = 12.0f * 1e-7f * (float)widen * fabsf(k->coef) * gmax;
-    const char *ek = getenv("FMD_CARRIER_K");           /* tuning / tests: override K (0 = never redo) */
+    const char *ek = tuning_env("FMD_CARRIER_K");       /* tuning builds: override K (0 = never redo) */
     if (ek) K = (float)atof(ek);
-    const char *es = getenv("FMD_CARRIER_SCALE");       /* ... or scale the derived K */
+    const char *es = tuning_env("FMD_CARRIER_SCALE");   /* ... or scale the derived K */
     if (es) K *= (float)atof(es);
     k->car_inv_k2 = K > 0.f ? 1.0f / (K * K) : 3.0e38f;
   }
@@ -481,6 +499,11 @@ void fmd_batch_destroy(fmd_batch *b) {
 int fmd_batch_pcm_stride(const fmd_batch *b) { return b ? b->pcm_stride : FMD_E_ARG; }
 int fmd_batch_n_streams(const fmd_batch *b) { return b ? b->n_streams : FMD_E_ARG; }
 int fmd_batch_math(const fmd_batch *b) { return b ? b->cfg.math : FMD_E_ARG; }
+int fmd_batch_set_time_split(fmd_batch *b, int workers_per_cu) {
+  if (!b) return fail(FMD_E_ARG, "NULL batch");
+  b->time_split = workers_per_cu;
+  return FMD_OK;
+}
 const char *fmd_batch_kernel_name(const fmd_batch *b) {
   return b ? fmdk_kernel_name(&b->kp, b->cfg.math) : "";
 }
@@ -503,9 +526,9 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   kp.n_streams = b->n_streams;
   kp.warm_tiles = fmdk_warm_tiles(&kp, b->cfg.math);
   kp.n_chunks = 1;
-  if (kp.warm_tiles > 0 && !getenv("FMD_NO_TIME_SPLIT")) {
-    const char *e_w = getenv("FMD_WORKERS_PER_CU");
-    const int per_cu = e_w ? atoi(e_w) : fmdk_workers_per_cu_mode(b->cfg.math, b->cfg.rate_out2 > 0 ? b->cfg.mode : 0);
+  if (kp.warm_tiles > 0 && b->time_split >= 0) {
+    const int per_cu = b->time_split > 0 ? b->time_split
+                                         : fmdk_workers_per_cu_mode(b->cfg.math, b->cfg.rate_out2 > 0 ? b->cfg.mode : 0);
     const long long m = kp.block_len >> 4, tile = fmdk_tile();
     const long long tiles = ((m + tile - 1) / tile) * n_blocks;
     long long want = ((long long)per_cu * b->n_cus + b->n_streams - 1) / b->n_streams;
@@ -907,9 +930,14 @@ static void ingest_detach(struct fmd_ingest *g) {
 
 void fmd_ingest_destroy(fmd_ingest *g) {
   if (!g) return;
+  pthread_mutex_lock(&g->m);
   fmd_batch *b = g->batch;
+  const int busy = g->inflight != 0 || g->debt != 0;     /* debt: in-flight bytes an overflow has moved out of `inflight` */
+  pthread_mutex_unlock(&g->m);
   if (b) {
-    if (g->inflight) {                 /* a job still reads this ring: let it finish first */
+    /* a queued H2D copy may still read this pinned ring: any job of the batch that holds ring bytes, whatever
+     * this ring's own counters say after an overflow - let it finish before the memory goes away */
+    if (busy || b->pump[0].ring_held || b->pump[1].ring_held) {
       hipSetDevice(b->device);
       batch_quiesce(b);
     }
@@ -997,20 +1025,15 @@ void fmd_ingest_callback(unsigned char *buf, uint32_t len, void *ctx) {
 uint32_t fmd_ingest_pop(fmd_ingest *g, uint8_t *out, uint32_t len) {
   if (!g || !out || len == 0 || len > g->cap) return 0;
   pthread_mutex_lock(&g->m);
-  if (g->size - g->inflight < len) { pthread_mutex_unlock(&g->m); return 0; }
-  const uint32_t from = (g->rpos + g->inflight) % g->cap;
+  /* jobs hold the bytes in front of these (they cannot be released out of order): nothing is copied then */
+  if (g->inflight != 0 || g->debt != 0 || g->size < len) { pthread_mutex_unlock(&g->m); return 0; }
+  const uint32_t from = g->rpos;
   uint32_t first = g->cap - from;
   if (first > len) first = len;
   memcpy(out, g->ring + from, first);
   memcpy(out + first, g->ring, len - first);
-  if (g->inflight == 0) {
-    g->rpos = (g->rpos + len) % g->cap;
-    g->size -= len;
-  } else {
-    /* jobs hold the bytes in front of these: cannot be released out of order */
-    pthread_mutex_unlock(&g->m);
-    return 0;
-  }
+  g->rpos = (g->rpos + len) % g->cap;
+  g->size -= len;
   pthread_mutex_unlock(&g->m);
   return len;
 }
@@ -1131,9 +1154,11 @@ int fmd_batch_pump_begin(fmd_batch *b, int max_blocks) {
   const size_t slots = (size_t)b->n_streams * (size_t)nb;
   if (e == hipSuccess) e = hipEventRecord(p->h2d_done, b->copy_stream);
   if (e == hipSuccess) e = hipStreamWaitEvent(b->stream, p->h2d_done, 0);
+  int launched = 0;
   if (e == hipSuccess) {
     rc = fmd_batch_run_device(b, p->d_iq, nb, p->d_pcm, p->d_lens, NULL);
     if (rc == FMD_OK) {
+      launched = 1;                                    /* the streams' state has advanced by nb blocks from here on */
       e = hipMemcpyAsync(p->h_pcm, p->d_pcm, slots * (size_t)b->pcm_stride * sizeof(int16_t), hipMemcpyDeviceToHost,
                          b->stream);
       if (e == hipSuccess)
@@ -1141,21 +1166,29 @@ int fmd_batch_pump_begin(fmd_batch *b, int max_blocks) {
       if (e == hipSuccess) e = hipEventRecord(p->done, b->stream);
     }
   }
-  if (e != hipSuccess || rc != FMD_OK) {
-    /* give the bytes back: wait for the copies already queued, then un-take them (they are still in
-     * the rings, so the next call sees them again) */
+  if (!launched) {
+    /* nothing has been demodulated: give the bytes back.  Wait for the copies already queued, then un-take them
+     * (they are still in the rings, so the next call sees them again); a part an overflow has meanwhile released
+     * (moved from inflight to debt) is not taken back a second time */
     hipStreamSynchronize(b->copy_stream);
     for (int s = 0; s < taken; s++) {
       fmd_ingest *g = b->ingest[s];
       pthread_mutex_lock(&g->m);
-      g->inflight -= take < g->inflight ? take : g->inflight;
+      uint32_t r = take;
+      const uint32_t d = g->debt < r ? g->debt : r;
+      g->debt -= d;
+      r -= d;
+      g->inflight -= r < g->inflight ? r : g->inflight;
       pthread_mutex_unlock(&g->m);
     }
     if (e != hipSuccess) return fail(FMD_E_HIP, "pump: %s (%d)", hipGetErrorString(e), (int)e);
     return rc;
   }
+  /* the kernel is queued: the job exists whatever happened to its D2H (un-taking the bytes now would demodulate
+   * the same blocks twice); a failed D2H is reported by fmd_batch_pump_end, which still releases the ring */
   p->n_blocks = nb;
   p->ring_held = 1;
+  p->failed = (e != hipSuccess) ? (int)e : 0;
   b->pump_head ^= 1;
   return nb;
 }
@@ -1167,6 +1200,18 @@ int fmd_batch_pump_end(fmd_batch *b, int16_t *pcm, int32_t *lens) {
   struct pump_slot *p = &b->pump[b->pump_tail];
   if (p->n_blocks <= 0) return 0;
   HIP_TRY(hipSetDevice(b->device));
+  if (p->failed) {
+    /* the job ran (state advanced) but its PCM never left the device: wait for the kernel, free the slot and the
+     * ring space, report */
+    const int err = p->failed;
+    hipStreamSynchronize(b->stream);
+    pump_release_ring(b, p);
+    p->n_blocks = 0;
+    p->failed = 0;
+    b->pump_tail ^= 1;
+    return fail(FMD_E_HIP, "pump: the job's device-to-host copy could not be queued: %s (%d); its %s", hipGetErrorString((hipError_t)err),
+                err, "blocks were demodulated and are lost");
+  }
   HIP_TRY(hipEventSynchronize(p->done));
   pump_release_ring(b, p);                           /* done implies its H2D is done */
   pump_release_completed(b);

@@ -37,12 +37,27 @@ def test_self_launch_two_ranks_gloo_dry_run():
 
 
 def test_gpus_beyond_device_count_fails_loudly():
-    """On a box without (enough) GPUs the real run refuses up front, with the reason."""
-    import torch
-    have = torch.cuda.device_count()
-    r = _run(["--gpus", str(have + 2), "--steps", "1", "--warmup", "0"])
+    """On a box without (enough) GPUs the real run refuses: up front from the driver's topology in sysfs where that is
+    readable (the launcher itself never opens a HIP device), otherwise when its ranks find no device."""
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.kfd_gpu_count()
+    n = (have or 0) + 2
+    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"])
     assert r.returncode != 0
-    assert "--gpus %d but this node shows %d HIP device" % (have + 2, have) in r.stderr
+    if have is not None:
+        assert "--gpus %d but this node shows %d HIP device" % (n, have) in r.stderr
+    else:
+        assert "rank exit codes" in r.stderr
+
+
+def test_launcher_does_not_import_torch():
+    """The parent of the ranks must not initialise HIP: no torch import on the launcher path."""
+    code = ("import sys; sys.argv = ['bench.py', '--gpus', '2', '--dry-run', '--steps', '1']; import bench; "
+            "bench.subprocess.Popen = lambda *a, **k: (_ for _ in ()).throw(SystemExit('torch' in sys.modules))")
+    r = subprocess.run([sys.executable, "-c", code + "; bench.main()"], capture_output=True, text=True, cwd=ROOT, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, (r.stdout, r.stderr)          # SystemExit(False) -> 0: torch was not imported
 
 
 def test_gpus_must_match_world_size():
@@ -52,6 +67,26 @@ def test_gpus_must_match_world_size():
 
 
 def test_failing_rank_fails_the_launch():
-    """A child that dies makes the launcher exit non-zero (here: rank environment the ranks reject)."""
+    """A rank that dies for real (rank 1 exits with 3 before the rendezvous) makes the launcher stop the other rank -
+    which would otherwise wait in the rendezvous for its timeout - and exit non-zero, promptly, leaving no child."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"], env={"FMD_BENCH_DRYRUN_FAIL_RANK": "1"},
+             timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 90
+    assert "rank 1 failed" in r.stderr and "3" in r.stderr
+    pids = [int(x) for l in r.stderr.splitlines() if l.startswith("bench.py: ranks ") for x in l.split()[2:]]
+    assert len(pids) == 2
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, "rank process %d left behind" % pid
+
+
+def test_gpus_below_one_is_rejected():
     r = _run(["--gpus", "0", "--dry-run"])
     assert r.returncode != 0

@@ -41,9 +41,10 @@ def oracle_run(cfg_kw, iq, block_len=BL):
     return pcm, lens, s
 
 
-def gpu_run(R, cfg_kw, iq, n_blocks, math, block_len=BL, launches=1, n_streams=1):
+def gpu_run(R, cfg_kw, iq, n_blocks, math, block_len=BL, launches=1, n_streams=1, time_split=0):
     cfg = R.wbfm_config(block_len=block_len, math=math, **cfg_kw)
     b = R.BatchDemod(cfg, n_streams)
+    b.set_time_split(time_split)
     per = n_blocks // launches
     iq = iq.reshape(n_streams, n_blocks, block_len)
     outs = [[] for _ in range(n_streams)]
@@ -404,17 +405,13 @@ def test_full_size_batch_properties(R):
         b.close()
 
 
-def test_chunking_does_not_change_results(R, lcg40, monkeypatch):
-    """The same launch with and without time chunks (FMD_NO_TIME_SPLIT) and with a different
-    worker target gives identical PCM and identical carried state."""
+def test_chunking_does_not_change_results(R, lcg40):
+    """The same launch without time chunks (fmd_batch_set_time_split < 0), with a different worker target and with
+    the default split gives identical PCM and identical carried state."""
     nb = 16
     outs, states = [], []
-    for env in ({"FMD_NO_TIME_SPLIT": "1"}, {"FMD_WORKERS_PER_CU": "3"}, {}):
-        for k in ("FMD_NO_TIME_SPLIT", "FMD_WORKERS_PER_CU"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got, lens, b = gpu_run(R, CONFIGS["stereo_300k"], lcg40[: nb * BL], nb, R.MATH_EXACT)
+    for split in (-1, 3, 0):
+        got, lens, b = gpu_run(R, CONFIGS["stereo_300k"], lcg40[: nb * BL], nb, R.MATH_EXACT, time_split=split)
         outs.append(got[0])
         st = b.get_state(0)
         states.append((st.acc, st.pre_r, st.pre_j, st.pp, st.deemph_l, st.deemph_r, list(st.br)[:90], list(st.bs)[:90]))
@@ -423,22 +420,18 @@ def test_chunking_does_not_change_results(R, lcg40, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
-def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, monkeypatch, name, fast_math):
+def test_chunking_fast_math_stays_within_one_lsb(R, lcg40, name, fast_math):
     """Fast kernels, whole tiles (the own-words decimator hands partial sums from lane to lane and from tile to tile):
     one worker for the whole launch, many short time chunks and the default split all stay within 1 LSB of the oracle,
     and the block lengths are the oracle's."""
     nb = 16
     want, wlens, _ = oracle_run(CONFIGS[name], lcg40[: nb * BL])
-    for env in ({"FMD_NO_TIME_SPLIT": "1"}, {"FMD_WORKERS_PER_CU": "3"}, {"FMD_WORKERS_PER_CU": "24"}, {}):
-        for k in ("FMD_NO_TIME_SPLIT", "FMD_WORKERS_PER_CU"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got, lens, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, fast_math)
+    for split in (-1, 3, 24, 0):
+        got, lens, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, fast_math, time_split=split)
         b.close()
-        assert np.array_equal(lens[0], wlens), env
+        assert np.array_equal(lens[0], wlens), split
         diff = int(np.abs(got[0].astype(np.int32) - want.astype(np.int32)).max())
-        assert diff <= 1, "%s %s: fast PCM differs from the oracle by %d LSB" % (name, env, diff)
+        assert diff <= 1, "%s time_split %s: fast PCM differs from the oracle by %d LSB" % (name, split, diff)
 
 
 def test_misaligned_iq_pointer_is_rejected(R):

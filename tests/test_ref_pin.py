@@ -40,6 +40,32 @@ EXTRA = {
 }
 
 
+def test_reference_library_is_the_pinned_one(tmp_path, monkeypatch):
+    """oracle/_ref/libref.so is what oracle/build_ref.py made from the reference lines whose hash is committed
+    (oracle/ref_pin.json), byte for byte as recorded at build time; bench.py times it as "the reference" only then."""
+    import json
+    import os
+    import shutil
+    from oracle import build_ref as B
+    st = B.ref_status()
+    assert st is not None and st["pinned"], st
+    assert st["slices_sha256"] == B.load_pin()["slices_sha256"]
+    assert st["so_sha256"] == st["so_sha256_on_disk"]
+    # a library that is not the recorded one, or lines that are not the pinned ones, are not "the reference"
+    fake = tmp_path / "_ref"
+    shutil.copytree(B.OUT, fake)
+    monkeypatch.setattr(B, "OUT", str(fake))
+    with open(fake / "libref.so", "ab") as f:
+        f.write(b"\0")
+    assert not B.ref_status()["pinned"]
+    shutil.copy(os.path.join(os.path.dirname(B.__file__), "_ref", "libref.so"), fake / "libref.so")
+    assert B.ref_status()["pinned"]
+    meta = json.load(open(fake / "libref.meta.json"))
+    meta["slices_sha256"] = "0" * 64
+    json.dump(meta, open(fake / "libref.meta.json", "w"))
+    assert not B.ref_status()["pinned"]
+
+
 def _both(cfg):
     return refbind.RefStream(**cfg), OracleStream(**cfg)
 
