@@ -57,8 +57,15 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D-inclusive leg (e2e_h2d)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra legs of the line: `sustained` (>= --sustained-seconds of back-to-back launches) "
+                         "and `noise_input` (the same workload on uniform random bytes, parity-checked)")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0)
     ap.add_argument("--e2e-streams", type=int, default=64)
-    ap.add_argument("--e2e-jobs", type=int, default=10)
+    ap.add_argument("--e2e-jobs", type=int, default=20)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) and run the counter gather through its collectives "
+                         "even with one rank: executes the multi-GPU branch on a one-GPU box")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / counter-gather plumbing only: no GPU work, gloo instead of RCCL (CPU tests)")
     ap.add_argument("--data", choices=["fm", "noise"], default="fm",
@@ -179,67 +186,22 @@ def cpu_baseline(cfg_kw, seconds, iq_dev=None):
     }
 
 
-def e2e_h2d(R, torch, cfg, iq_dev, n_streams, n_blocks, n_jobs, device):
-    """IQ that starts in HOST memory: rtlsdr-callback-shaped ingest (fmd_ingest_callback, one
-    262144-byte transfer at a time, fed by host threads as the dongle threads would) -> pinned
-    rings -> fmd_batch_pump_begin / _end with two jobs in flight (staging + H2D of job k+1 beside
-    the kernel of job k) -> PCM back in host memory.  Wall clock over everything, first callback to
-    last PCM.  Roles: src/rtl_fm_player.c:790-837 (callback), :855-933 (demod thread)."""
-    import ctypes as C
-    L = R.lib()
-    b = R.BatchDemod(cfg, n_streams, device=device)
-    host = np.ascontiguousarray(iq_dev[:n_streams, :n_blocks].cpu().numpy()).reshape(n_streams, n_blocks, BLOCK_LEN)
-    rings = []
-    for s in range(n_streams):
-        h = C.c_void_p()
-        # ring = two jobs: a job's bytes stay in the ring until their H2D is done (zero-copy pump), the
-        # producers meanwhile fill the other half
-        rc = L.fmd_ingest_create(C.byref(h), b._h, s, 2 * n_blocks * BLOCK_LEN)
-        if rc:
-            raise RuntimeError("fmd_ingest_create: %d" % rc)
-        rings.append(h)
+def e2e_h2d(mode, n_streams, n_blocks, n_jobs, math_name):
+    """IQ that starts in HOST memory, measured without Python in the loop: rtl_fm_player_amd/fmd_e2e_bench (C, csrc/
+    fmd_e2e_bench.c) runs as a child process - feeder pthreads in the dongle threads' role call fmd_ingest_callback one
+    262144-byte transfer at a time (src/rtl_fm_player.c:790-837), its main thread is the demod thread (:855-933):
+    fmd_batch_pump_begin / _end with two jobs in flight, H2D straight from the pinned rings, PCM back in host memory.
+    Wall clock over everything.  (Round 2 fed the rings from Python threads: 12 GB/s, the harness's own limit.)"""
+    exe = os.path.join(ROOT, "rtl_fm_player_amd", "fmd_e2e_bench")
+    if not os.path.isfile(exe):
+        raise RuntimeError("rtl_fm_player_amd/fmd_e2e_bench not built (python -c 'import __graft_entry__ as g; g.build()')")
     n_thr = max(1, min(usable_cores(), n_streams, 16))
-
-    def feed(t):
-        for s in range(t, n_streams, n_thr):
-            for k in range(n_blocks):
-                L.fmd_ingest_callback(host[s, k].ctypes.data, BLOCK_LEN, rings[s])
-
-    def fill():
-        thr = [threading.Thread(target=feed, args=(t,)) for t in range(n_thr)]
-        [x.start() for x in thr]
-        [x.join() for x in thr]
-
-    pcm = np.zeros((n_streams, n_blocks, b.pcm_stride), dtype=np.int16)
-    lens = np.zeros((n_streams, n_blocks), dtype=np.int32)
-
-    def run(jobs):
-        fill()
-        assert L.fmd_batch_pump_begin(b._h, n_blocks) == n_blocks, L.fmd_last_error()
-        for _ in range(1, jobs):
-            fill()                                              # overlaps the job in flight
-            assert L.fmd_batch_pump_begin(b._h, n_blocks) == n_blocks, L.fmd_last_error()
-            assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == n_blocks
-        assert L.fmd_batch_pump_end(b._h, pcm.ctypes.data, lens.ctypes.data) == n_blocks
-
-    run(2)                                                      # buffers allocated, clocks up
-    t0 = time.perf_counter()
-    run(n_jobs)
-    dt = time.perf_counter() - t0
-    nbytes = n_jobs * n_streams * n_blocks * BLOCK_LEN
-    out = {
-        "value": round(nbytes / 2 / dt / 1e6, 1), "unit": "Msamples/s",
-        "pcie_gbs": round(nbytes / dt / 1e9, 2),
-        "streams": n_streams, "blocks_per_job": n_blocks, "jobs": n_jobs, "feeder_threads": n_thr,
-        "ms_per_job": round(dt / n_jobs * 1e3, 3),
-        "path": "host IQ -> fmd_ingest_callback (262144-byte transfers, %d host threads) -> pinned rings (2 jobs "
-                "deep) -> H2D straight from the rings, fmd_batch_pump_begin/_end with two jobs in flight -> PCM in "
-                "host memory; wall clock" % n_thr,
-    }
-    for h in rings:
-        L.fmd_ingest_destroy(h)
-    b.close()
-    return out
+    cmd = [exe, "-S", str(n_streams), "-B", str(n_blocks), "-J", str(max(2, n_jobs)), "-T", str(n_thr),
+           "-m", "1" if mode in ("mono", "nfm") else "2"] + (["-e"] if math_name == "exact" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("fmd_e2e_bench failed: " + r.stderr[-500:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def copy_bandwidth(torch, dev, stream, nbytes=1 << 30):
@@ -428,9 +390,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:             # --force-dist without a launcher: a free port of our own
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     stereo = args.mode == "stereo"
@@ -438,9 +404,9 @@ def main():
         cfg_kw = dict(rate_in=25000, rate_out2=12500, mode=1)          # BASELINE.json configs[4]
     else:
         cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
-    math = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
+    math_code = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
             "fast-mfma-c": R.MATH_FAST_MFMA_C}[args.math]
-    cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math, **cfg_kw)
+    cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math_code, **cfg_kw)
     S, B = args.streams, args.blocks
     batch = R.BatchDemod(cfg, S, device=local)
 
@@ -461,13 +427,13 @@ def main():
         batch.run_device(iq, B, pcm, lens, hip_stream=stream.cuda_stream)
 
     # ---- parity gate: EVERY stream of this rank against the oracle (host threads; the oracle releases the GIL) ----
-    parity = None
-    if not args.no_check:
+    def parity_gate(iq_t):
         from concurrent.futures import ThreadPoolExecutor
         from oracle import OracleStream
-        step()
+        batch.reset()
+        batch.run_device(iq_t, B, pcm, lens, hip_stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
-        h_iq, h_pcm, h_lens = iq.cpu().numpy(), pcm.cpu().numpy(), lens.cpu().numpy()
+        h_iq, h_pcm, h_lens = iq_t.cpu().numpy(), pcm.cpu().numpy(), lens.cpu().numpy()
         tol = 0 if args.math == "exact" else 1
 
         def check(s):
@@ -483,9 +449,24 @@ def main():
         assert worst < (1 << 20), "result_len mismatch on stream %d" % diffs.index(worst)
         assert worst <= tol, "PCM of stream %d differs from the CPU oracle by %d LSB (tolerance %d)" % (
             diffs.index(worst), worst, tol)
-        parity = {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": S}
-        del h_iq, h_pcm, h_lens
         batch.reset()
+        return {"max_abs_lsb": worst, "tolerance_lsb": tol, "streams_checked": S}
+
+    def timed_launches(iq_t, n):
+        """n back-to-back launches on `stream` between one HIP event pair: (wall seconds, kernel ms per launch)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        w0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(n):
+            batch.run_device(iq_t, B, pcm, lens, hip_stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - w0, e0.elapsed_time(e1) / n
+
+    parity = None
+    if not args.no_check:
+        parity = parity_gate(iq)
 
     batch.set_timing(False)                                  # no per-launch event pair inside the library
     for _ in range(max(0, args.preheat - args.warmup)):     # clock settling, see --preheat
@@ -517,8 +498,34 @@ def main():
     # ---- gather the per-rank counters over RCCL (no data-path collective) ----
     from rtl_fm_player_amd.shard import gather_counters
     rep = gather_counters(dist, dev, elapsed, samples_per_step * args.steps, int(kernel_ms * 1e6),
-                          int(pcm.view(torch.int16).sum().item()))
+                          int(pcm.view(torch.int16).sum().item()), force=args.force_dist)
     total_samples, elapsed = rep["samples"], rep["elapsed_s"]
+
+    # ---- extra legs (never `value`): a sustained run and the worst-case input ----
+    sustained = noise_leg = None
+    if not args.no_extra and not args.dry_run:
+        n_sus = max(args.steps, int(math.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
+        wall, k_ms = timed_launches(iq, n_sus)
+        sustained = {"launches": n_sus, "seconds": round(wall, 3), "ms_per_step": round(wall / n_sus * 1e3, 4),
+                     "kernel_ms": round(k_ms, 4), "value": round(samples_per_step * n_sus / wall / 1e6, 1),
+                     "frac": round(algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "back-to-back launches of the timed workload right after the timed region; whole-rank rate"}
+        if args.data != "noise":
+            # uniform random bytes = a pilot-less, full-band input: the ill-conditioned-sample redo paths of the +-1 LSB
+            # kernels (branch cut / origin of the discriminator, carrier regeneration without a pilot) run here
+            gn = torch.Generator(device=dev)
+            gn.manual_seed(54321 + rank)
+            iq_n = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gn)
+            torch.cuda.synchronize(dev)
+            par_n = None if args.no_check else parity_gate(iq_n)
+            timed_launches(iq_n, max(2, args.warmup))
+            wall, k_ms = timed_launches(iq_n, args.steps)
+            noise_leg = {"data": "synthetic uniform random bytes", "steps": args.steps,
+                         "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(k_ms, 4),
+                         "value": round(samples_per_step * args.steps / wall / 1e6, 1), "parity": par_n,
+                         "slowdown_vs_timed_input": round(k_ms / kernel_ms, 3)}
+            del iq_n
+            batch.reset()
 
     if rank == 0:
         copy_gbs = copy_bandwidth(torch, dev, stream) if S * B * BLOCK_LEN <= (1 << 31) else 0.0
@@ -582,13 +589,19 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if parity:
             out["parity"] = parity
+        if sustained:
+            out["sustained"] = sustained
+        if noise_leg:
+            out["noise_input"] = noise_leg
         out["per_rank"] = rep["per_rank"]                      # samples, kernel ns per launch, PCM checksum of each rank
+        if rep.get("backend"):
+            out["counters_gathered_over"] = rep["backend"]     # "nccl" (= RCCL): all_reduce(MAX) + all_gather ran
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds, iq)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         if not args.no_e2e and world == 1:
-            out["e2e_h2d"] = e2e_h2d(R, torch, cfg, iq, min(args.e2e_streams, S), B, args.e2e_jobs, local)
+            out["e2e_h2d"] = e2e_h2d(args.mode, min(args.e2e_streams, S), B, args.e2e_jobs, args.math)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -14,15 +14,16 @@ def shard_streams(total_streams, world, rank):
     return first, count
 
 
-def gather_counters(dist, device, elapsed_s, samples, kernel_ns, checksum):
+def gather_counters(dist, device, elapsed_s, samples, kernel_ns, checksum, force=False):
     """Whole-job view of a timed region.
 
     elapsed is reduced with MAX (the job is as slow as its slowest rank); samples, kernel time
     and the PCM checksum are all-gathered.  Returns a dict (identical on every rank).  `dist` is
-    the torch.distributed module or None for a single process.
+    the torch.distributed module or None for a single process.  force: go through the collectives even with one
+    rank (bench.py --force-dist: the RCCL branch executed on the one GPU a development box has).
     """
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return {"world": 1, "elapsed_s": float(elapsed_s), "samples": int(samples),
                 "per_rank": [{"samples": int(samples), "kernel_ns": int(kernel_ns), "checksum": int(checksum)}]}
     world = dist.get_world_size()
@@ -33,4 +34,4 @@ def gather_counters(dist, device, elapsed_s, samples, kernel_ns, checksum):
     dist.all_gather(allc, mine)
     per_rank = [{"samples": int(c[0]), "kernel_ns": int(c[1]), "checksum": int(c[2])} for c in allc]
     return {"world": world, "elapsed_s": float(el.item()), "samples": sum(r["samples"] for r in per_rank),
-            "per_rank": per_rank}
+            "per_rank": per_rank, "backend": dist.get_backend()}

@@ -55,3 +55,25 @@ def test_single_process_passthrough():
     rep = gather_counters(None, torch.device("cpu"), 0.5, 10, 3, 7)
     assert rep == {"world": 1, "elapsed_s": 0.5, "samples": 10,
                    "per_rank": [{"samples": 10, "kernel_ns": 3, "checksum": 7}]}
+
+
+def _worker_forced(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = gather_counters(dist, torch.device("cpu"), 0.5, 10, 3, 7, force=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_with_one_rank():
+    """bench.py --force-dist: with one rank the gather still goes through all_reduce / all_gather (gloo here, RCCL under
+    -m gpu) and reports the backend."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_forced, args=(1, port, out), nprocs=1, join=True)
+    assert out[0] == {"world": 1, "elapsed_s": 0.5, "samples": 10, "backend": "gloo",
+                      "per_rank": [{"samples": 10, "kernel_ns": 3, "checksum": 7}]}

@@ -122,3 +122,24 @@ def test_bench_line_contract(R):
     assert set(cb["configs_single_thread"]) == {"mono_2.4Msps", "stereo_2.4Msps", "nfm_200ksps"}
     assert d["parity"]["max_abs_lsb"] <= 1 and d["e2e_h2d"]["value"] > 100 and d["e2e_h2d"]["pcie_gbs"] > 0.2
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["kernel_ns"] > 0
+
+
+def test_rccl_counter_gather_runs_on_one_gpu(R):
+    """The multi-GPU branch of bench.py executed where only one GPU exists: `--force-dist` initialises
+    torch.distributed with backend nccl (= RCCL) at world size 1, on this rank's device, runs the barriers and the
+    all_reduce(MAX) / all_gather of the counters through it, and still prints the one JSON line."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "4",
+                        "--warmup", "1", "--preheat", "2", "--streams", "16", "--blocks", "2", "--no-cpu", "--no-e2e"],
+                       capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["counters_gathered_over"] == "nccl" and d["n_gpus"] == 1
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["samples"] == 16 * 2 * 131072 * 4
+    assert d["parity"]["max_abs_lsb"] <= 1

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 for m in "${MODES[@]}"; do
   for round in 1 2; do
     for f in ${FAMILIES:-0 1}; do
-      FMD_MFMA=$f timeout 300 python3 bench.py --steps 100 --no-cpu --no-e2e --mode $m "$@" > $OUT/ab_${m}_mfma${f}_r$round.json 2>> $OUT/ab.err
+      FMD_MFMA=$f timeout 300 python3 bench.py --steps 100 --no-cpu --no-e2e --no-extra --mode $m "$@" > $OUT/ab_${m}_mfma${f}_r$round.json 2>> $OUT/ab.err
       python3 - $OUT/ab_${m}_mfma${f}_r$round.json $m $f $round <<'PY'
 import json,sys
 try:

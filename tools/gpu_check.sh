@@ -10,7 +10,7 @@ if [ $MODE = full ]; then
   grep -h "MISMATCH\|^seed" $OUT/fuzz*.log
 fi
 for m in stereo mono nfm; do
-  timeout 300 python bench.py --steps 100 --no-cpu --no-e2e --mode $m > $OUT/bench_$m.json 2>> $OUT/bench.err
+  timeout 300 python bench.py --steps 100 --no-cpu --no-e2e --no-extra --mode $m > $OUT/bench_$m.json 2>> $OUT/bench.err
   python - $OUT/bench_$m.json $m <<'PY'
 import json,sys
 try:

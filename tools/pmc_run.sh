@@ -5,7 +5,7 @@ set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 CNT="$1"; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-include-regex fmd_fused --pmc $CNT --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-check "$@" > /dev/null 2>&1 || true
+rocprofv3 --kernel-include-regex fmd_fused --pmc $CNT --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-extra --no-check "$@" > /dev/null 2>&1 || true
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()

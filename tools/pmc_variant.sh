@@ -3,7 +3,7 @@
 LIB=$1; CNT="$2"
 OUT=/tmp/pmcv_$$
 cd /tmp && export TMPDIR=/tmp
-FMD_LIB_PATH=$LIB rocprofv3 --kernel-include-regex fmd_fused --pmc $CNT --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-check "${@:3}" > /dev/null 2>&1 || true
+FMD_LIB_PATH=$LIB rocprofv3 --kernel-include-regex fmd_fused --pmc $CNT --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-extra --no-check "${@:3}" > /dev/null 2>&1 || true
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)

@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/prof_$TAG            # raw rocprofv3 output stays on the box (tens of MiB); the summary travels
 rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-e2e $*"
-PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-check $*"   # counters serialise launches: few steps
+BENCH="python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-e2e --no-extra $*"
+PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --preheat 0 --no-cpu --no-e2e --no-extra --no-check $*"   # counters serialise launches: few steps
 echo "== bench (unprofiled)"; timeout 300 $BENCH | tee $OUT/bench_unprofiled.json
 echo "== kernel trace + stats"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_traced.json 2>$OUT/trace.log
