@@ -579,3 +579,72 @@ def test_full_size_every_stream_against_the_oracle(R, mode):
             worst = max(worst, d)
             assert d <= tol, "math %d stream %d: |diff| %d" % (math, s, d)
         b.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(rate_in=300000, rate_out2=48000, mode=2),
+    dict(rate_in=48000, rate_out2=16000, mode=2),          # the wide pilot filter (fmd_host.c: K grows with sum fp^2)
+], ids=["300k", "48k"])
+@pytest.mark.parametrize("via", ["run_device", "pump"])
+def test_fast_hand_over_between_one_block_launches(R, fast_math, kw, via):
+    """Real-time use: ONE reference block per launch, so every launch's first `size` samples reach back into what the
+    launch before handed over.  Noise input (no pilot: the carrier redo fires every few tiles, and with 64 streams x 64
+    launches many of those samples lie in that window), every stream within 1 LSB of the oracle - through
+    fmd_batch_run_device and through the ingest rings + fmd_batch_pump.  The hand-over is exact: the last decimated
+    sample and the last `size` discriminator outputs are carried in the reference's own bits
+    (src/rtl_fm_player.c:430-436, :533-568 carry exact rings from block to block)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import OracleStream
+    S, NL = 64, 64
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    iq = torch.randint(0, 256, (S, NL, BL), dtype=torch.uint8, device=dev, generator=g)
+    torch.cuda.synchronize()
+    h_iq = iq.cpu().numpy()
+    b = R.BatchDemod(R.wbfm_config(math=fast_math, **kw), S)
+    got = [[] for _ in range(S)]
+    glens = np.zeros((S, NL), dtype=np.int32)
+    if via == "run_device":
+        pcm = torch.zeros((S, 1, b.pcm_stride), dtype=torch.int16, device=dev)
+        lens = torch.zeros((S, 1), dtype=torch.int32, device=dev)
+        for k in range(NL):
+            blk = iq[:, k:k + 1].contiguous()
+            torch.cuda.synchronize()
+            b.run_device(blk, 1, pcm, lens)
+            b.sync()
+            p, l = pcm.cpu().numpy(), lens.cpu().numpy()
+            glens[:, k] = l[:, 0]
+            for s in range(S):
+                got[s].append(p[s, 0, :l[s, 0]].copy())
+    else:
+        L = R.lib()
+        rings = []
+        for s in range(S):
+            h = C.c_void_p()
+            assert L.fmd_ingest_create(C.byref(h), b._h, s, 0) == 0
+            rings.append(h)
+        pcm = np.zeros((S, 1, b.pcm_stride), dtype=np.int16)
+        lens = np.zeros((S, 1), dtype=np.int32)
+        for k in range(NL):
+            for s in range(S):
+                blk = np.ascontiguousarray(h_iq[s, k])
+                L.fmd_ingest_callback(blk.ctypes.data, BL, rings[s])
+            assert L.fmd_batch_pump(b._h, 1, pcm.ctypes.data, lens.ctypes.data) == 1
+            glens[:, k] = lens[:, 0]
+            for s in range(S):
+                got[s].append(pcm[s, 0, :lens[s, 0]].copy())
+        for h in rings:
+            L.fmd_ingest_destroy(h)
+
+    def check(s):
+        want, wl = OracleStream(**kw).run(h_iq[s].reshape(-1), BL)
+        if not np.array_equal(glens[s], wl):
+            return 1 << 20
+        return int(np.abs(np.concatenate(got[s]).astype(np.int32) - want.astype(np.int32)).max())
+
+    with ThreadPoolExecutor(16) as ex:
+        diffs = list(ex.map(check, range(S)))
+    b.close()
+    assert max(diffs) <= 1, "stream %d: |diff| %d" % (diffs.index(max(diffs)), max(diffs))
