@@ -213,7 +213,7 @@ typedef struct fmd_stream_state {
 typedef struct fmd_debug_taps {
   void *y, *v, *mpx;
   void *prof;   /* i64 [n_streams][16]: shader-clock cycles per stage, summed over the launch
-                   (0 load, 1 decimate, 2 discriminate, 3 q1, 4 mpx, 5 carrier, 6 resample,
+                   (0 load, 1 decimate, 2 discriminate, 3 q1, 4 mpx, 5 per-tile flush of the fast kernels, 6 resample,
                     7 roll, 8 flush, 9 state in/out, 15 total) */
 } fmd_debug_taps;
 

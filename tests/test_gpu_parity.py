@@ -648,3 +648,33 @@ def test_fast_hand_over_between_one_block_launches(R, fast_math, kw, via):
         diffs = list(ex.map(check, range(S)))
     b.close()
     assert max(diffs) <= 1, "stream %d: |diff| %d" % (diffs.index(max(diffs)), max(diffs))
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_same_input_same_output_soak(R, fast_math, mode):
+    """Determinism under full occupancy: 256 streams fed the SAME IQ (noise) for 10 launches of 16 blocks - every
+    stream's PCM must equal stream 0's bit for bit, every launch.  Workers of one SIMD share the vector ALU, the matrix
+    pipe and LDS; nothing one of them does may reach another's results.  (Round 3 measured a split-bf16 MFMA form of
+    stage C that failed exactly this - about one tile in a thousand, only with two or more workers per SIMD - while
+    passing every single-stream parity test: tools/experiments/mpx_tile_bf16.inc.)"""
+    import torch
+    from oracle import lcg_bytes
+    S, B = 256, 16
+    dev = torch.device("cuda:0")
+    one = torch.from_numpy(lcg_bytes(B * BL, 2024)[0]).to(dev).view(1, B * BL)
+    iq = one.expand(S, B * BL).contiguous()
+    b = R.BatchDemod(R.wbfm_config(math=fast_math, rate_in=300000, rate_out2=48000, mode=mode), S)
+    pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+    lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    first = None
+    for rep in range(10):
+        b.reset()
+        b.run_device(iq, B, pcm, lens)
+        b.sync()
+        p = pcm.view(S, -1)
+        if first is None:
+            first = p[0].clone()
+        odd = int((p != first.unsqueeze(0)).any(dim=1).sum().item())
+        assert odd == 0, "launch %d: %d of %d streams differ from stream 0 of the first launch" % (rep, odd, S)
+    b.close()

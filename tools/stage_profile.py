@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-NAMES = ["load", "decimate", "discriminate", "q1", "mpx", "carrier", "resample", "roll", "flush", "state"]
+NAMES = ["load", "decimate", "discriminate", "q1", "mpx", "flush_fast", "resample", "roll", "flush", "state"]
 
 
 def main():
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--math", default="fast")
     ap.add_argument("--mode", default="stereo")
+    ap.add_argument("--data", default="fm")
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
     import torch

@@ -64,6 +64,17 @@ __global__ __launch_bounds__(512) void k(float *out, int nm, int nv, float a, fl
         c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c3, 0, 0, 0);
       }
       r = c0[0] + c1[1] + c2[2] + c3[3];
+    } else if constexpr (MT == 6) {
+      typedef short s4v __attribute__((ext_vector_type(4)));
+      f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+      s4v x = {(short)threadIdx.x, 3, 5, 7}, y = {(short)(a * 100), 1, 2, 3};
+      for (int i = 0; i < nm; i += 4) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c3, 0, 0, 0);
+      }
+      r = c0[0] + c1[1] + c2[2] + c3[3];
     } else if constexpr (MT == 3) {
       i4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
       i4 x = {(int)threadIdx.x, 3, 5, 7}, y = {(int)(a * 100), 1, 2, 3};
@@ -133,6 +144,7 @@ int main() {
   pair<1>("f32 16x16x4", d, 1 << 16, 32);
   pair<5>("f32 32x32x2", d, 1 << 15, 64);
   pair<2>("bf16 16x16x32", d, 1 << 17, 16);
+  pair<6>("bf16 16x16x16", d, 1 << 17, 8);
   pair<4>("f16 16x16x32", d, 1 << 17, 16);
   pair<3>("i8 16x16x64", d, 1 << 17, 16);
   return 0;
