@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Soak (GPU box): the determinism soak of tools/diag/determinism.py with a NEIGHBOUR on every SIMD that only issues matrix
+instructions (tools/diag/coburst.hip, its own stream, started before the product's launches).  Every stream of every launch
+must equal the PCM of a launch made without the neighbour.
+  python tools/diag/coburst.py <math code> <launches> <mode 2|1> <kind 0 bf16 | 1 i8 | 2 f32 | 3 valu> [blocks] [prio]"""
+import ctypes, os, subprocess, sys, time
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
+import torch
+import rtl_fm_player_amd as R
+from oracle import lcg_bytes
+math, n, mode, kind = (int(x) for x in sys.argv[1:5])
+blocks = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+prio = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+so = os.path.join(here, "libcoburst.so")
+if not os.path.exists(so):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(here, "coburst.hip")], check=True)
+co = ctypes.CDLL(so)
+BL, S, B = 262144, 256, 16
+dev = torch.device("cuda:0")
+one = torch.from_numpy(lcg_bytes(B * BL, 2024)[0]).to(dev).view(1, B * BL)
+iq = one.expand(S, B * BL).contiguous()
+b = R.BatchDemod(R.wbfm_config(math=math, rate_in=300000, rate_out2=48000, mode=mode), S)
+pcm = torch.zeros((S, B, b.pcm_stride), dtype=torch.int16, device=dev)
+lens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+
+def launches(k):
+    bad_l = bad_s = 0
+    t0 = time.time()
+    for rep in range(k):
+        b.reset()
+        b.run_device(iq, B, pcm, lens); b.sync()
+        p = pcm.view(S, -1)
+        d = int((p != first.unsqueeze(0)).any(dim=1).sum().item())
+        if os.environ.get("CB_CPU_COMPARE"):         # the same comparison on the host, from a copy made by the runtime's DMA
+            h = p.cpu().numpy()
+            dc = int((h != first_h[None, :]).any(axis=1).sum())
+            if dc != d:
+                global disagree
+                disagree += 1
+                if disagree <= 3:
+                    n_gpu = int((p != first.unsqueeze(0)).sum().item())
+                    print("  launch", rep, ": device-side comparison says", d, "streams deviate (", n_gpu, "values ), host-side comparison of the same buffer says", dc)
+            d = dc
+        bad_l += d > 0; bad_s += d
+    return bad_l, bad_s, (time.time() - t0) / k * 1e3
+
+b.reset(); b.run_device(iq, B, pcm, lens); b.sync()
+first = pcm.view(S, -1)[0].clone()
+first_h = first.cpu().numpy()
+disagree = 0
+alone = launches(20)
+tot_l = tot_s = done = 0
+ms = []
+while done < n:
+    k = min(200, n - done)                     # a neighbour lives a few seconds at most: restart it every 200 launches
+    rc = co.coburst_start(kind, blocks, prio)
+    assert rc == 0, rc
+    time.sleep(0.05)
+    bl, bs, t = launches(k)
+    rc = co.coburst_stop()
+    assert rc == 0, rc
+    tot_l += bl; tot_s += bs; done += k; ms.append(t)
+print("family", b.math, "mode", mode, "neighbour kind", kind, "blocks", blocks, "prio", prio, "| alone: deviating", alone[1], "ms/launch(host)", round(alone[2], 3),
+      "| with neighbour: launches", n, "launches with a deviating stream", tot_l, "deviating stream-launches", tot_s, "of", n * S,
+      "ms/launch(host)", [round(x, 3) for x in ms], "| launches where device-side and host-side comparison disagree:", disagree if os.environ.get("CB_CPU_COMPARE") else "n/a")
