@@ -2,7 +2,7 @@
 // (tools/diag/coburst.py: the fused kernels' PCM changes under such a neighbour; v_mfma_f32_16x16x4_f32 and plain VALU
 // neighbours change nothing.)  One kernel per instruction family ("chain"); every wave of the grid runs the same chain on
 // the same lane-dependent data, so every wave's 64 results must equal the ones of a launch made without the neighbour.
-//   hipcc --offload-arch=gfx950 -O3 -o valu_zoo valu_zoo.hip && ./valu_zoo [neighbour kind 0 bf16 | 1 i8 | 2 f32 | 3 valu] [reps]
+//   hipcc --offload-arch=gfx950 -O3 -o valu_zoo valu_zoo.hip && ./valu_zoo [neighbour kind 0 bf16 | 1 i8 | 2 f32 | 3 valu] [reps] [iterations] [first chain] [s_setprio of the chains' waves]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +59,10 @@ static const char *chain_name[] = {
 constexpr int N_CHAINS = 27;
 
 template <int CH>
-__global__ void __launch_bounds__(256) zoo(unsigned *out, const uint4 *pattern, int iters, float sk0, float sk1, const f4 *ftab) {
+__global__ void __launch_bounds__(256) zoo(unsigned *out, const uint4 *pattern, int iters, float sk0, float sk1, const f4 *ftab, int prio) {
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  if (prio == 3) __builtin_amdgcn_s_setprio(3);
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float x = 0.25f + 0.001f * lane, y = -0.5f + 0.002f * lane, z = 0.125f;
@@ -254,9 +257,10 @@ __global__ void __launch_bounds__(256) zoo(unsigned *out, const uint4 *pattern, 
 }
 
 static const f4 *g_ftab;
+static int g_prio;
 template <int CH>
 static void launch_zoo(hipStream_t st, int grid, unsigned *out, const uint4 *pat, int iters) {
-  hipLaunchKernelGGL(zoo<CH>, dim3(grid), dim3(256), 0, st, out, pat, iters, 0.999f, 0.5f, g_ftab);
+  hipLaunchKernelGGL(zoo<CH>, dim3(grid), dim3(256), 0, st, out, pat, iters, 0.999f, 0.5f, g_ftab, g_prio);
 }
 typedef void (*launch_fn)(hipStream_t, int, unsigned *, const uint4 *, int);
 static launch_fn launchers[N_CHAINS] = {launch_zoo<0>, launch_zoo<1>, launch_zoo<2>, launch_zoo<3>, launch_zoo<4>, launch_zoo<5>, launch_zoo<6>, launch_zoo<7>,
@@ -266,6 +270,7 @@ int main(int argc, char **argv) {
   const int kind = argc > 1 ? atoi(argv[1]) : 0, reps = argc > 2 ? atoi(argv[2]) : 5;
   const int grid = 256 * 3, iters = argc > 3 ? atoi(argv[3]) : 4000;
   const int first_chain = argc > 4 ? atoi(argv[4]) : 0;
+  g_prio = argc > 5 ? atoi(argv[5]) : 0;                 /* s_setprio of the zoo's waves (the neighbour stays at 0) */
   hipStream_t s1, s2;
   CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   int *stop; CHECK(hipHostMalloc((void **)&stop, 64, hipHostMallocMapped));
@@ -282,7 +287,7 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(ftab, hf.data(), hf.size() * sizeof(f4), hipMemcpyHostToDevice));
   g_ftab = ftab;
   std::vector<unsigned> ref((size_t)grid * 256), got((size_t)grid * 256);
-  printf("neighbour kind %d (0 bf16 16x16x32, 1 i8 16x16x64, 2 f32 16x16x4, 3 v_fma), %d waves per chain and launch, %d launches\n", kind, grid * 4, reps);
+  printf("neighbour kind %d (0 bf16 16x16x32, 1 i8 16x16x64, 2 f32 16x16x4, 3 v_fma), %d waves per chain and launch, %d launches, s_setprio %d\n", kind, grid * 4, reps, g_prio);
   for (int ch = first_chain; ch < N_CHAINS; ch++) {
     launchers[ch](s1, grid, out, pat, iters);
     CHECK(hipStreamSynchronize(s1));
