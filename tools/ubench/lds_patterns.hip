@@ -37,14 +37,23 @@ __global__ void __launch_bounds__(256) lds_pattern(float *out, int iters) {
     case 5: case 8: q = 4 * (lane & 15) + (lane >> 4); base += 8 * ((25 * q) >> 2); break;
     case 6: q = lane >> 2; base += 4 * (((25 * q) >> 2) + 8 * (lane & 3)); break;
     case 7: base += 4 * ((25 * lane) >> 2); break;
+    case 9: q = lane >> 2; base += 4 * (((25 * q + 3) >> 2) + 160 - 8 * (lane & 3)); break;              /* high side of the mono window: x[i - 8 o - k] */
+    case 10: q = lane >> 2; base += (q < 2) ? 4 * (((25 * q) >> 2) + 8 * (lane & 3)) : 0; break;        /* last pass: 2 frames live, the other lanes read one address */
+    case 12: base += 16 * lane; break;                                                               /* ds_read2_b64, ideal */
+    case 13: q = (lane >> 5) + 4 * ((lane >> 2) & 7); base += 4 * (((25 * q + 1) >> 2) + 8 * (lane & 3)); break;   /* mono stage D, every 4th frame per cycle, other phase */
+    case 14: q = (lane >> 5) + 4 * ((lane >> 2) & 7); base += 4 * (((25 * q + 2) >> 2) + 160 - 8 * (lane & 3)); break;   /* ... high side, third phase */
+    case 11: q = 16 + (lane >> 2); base += 4 * (((25 * q + 1) >> 2) + 8 * (lane & 3)); break;           /* second pass of an iteration (frames 16 .. 31), other phase */
   }
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; it++) {
     // eight reads per iteration at immediate offsets, like the unrolled stages
-    if constexpr (PAT == 0 || PAT == 1 || PAT == 6 || PAT == 7) {
+    if constexpr (PAT == 0 || PAT == 1 || PAT == 6 || PAT == 7 || (PAT >= 9 && PAT != 12)) {
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(4 * k));
+      for (int k = 0; k < 8; k++) {
+        if constexpr (PAT == 9 || PAT == 14) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(4 * (7 - k)));
+        else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(4 * k));
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
       for (int k = 0; k < 8; k++) acc.x += v[k];
@@ -59,7 +68,7 @@ __global__ void __launch_bounds__(256) lds_pattern(float *out, int iters) {
       f4 v[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        if constexpr (PAT == 8) asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v[k]) : "v"(base), "n"(2 * k), "n"(2 * k + 1));
+        if constexpr (PAT == 8 || PAT == 12) asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v[k]) : "v"(base), "n"(2 * k), "n"(2 * k + 1));
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(16 * k));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
@@ -96,5 +105,11 @@ int main() {
   run<6>(d, "b32 mono stage D, four lanes per frame", 4);
   run<7>(d, "b32 mono stage D, frame per lane", 4);
   run<8>(d, "ds_read2_b64 stereo stage D", 16);
+  run<9>(d, "b32 mono stage D, four lanes per frame, high side (descending)", 4);
+  run<10>(d, "b32 mono stage D, last pass (2 of 16 frames live)", 4);
+  run<11>(d, "b32 mono stage D, frames 16..31", 4);
+  run<12>(d, "ds_read2_b64 ideal", 16);
+  run<13>(d, "b32 mono stage D, every 4th frame per LDS cycle, low side", 4);
+  run<14>(d, "b32 mono stage D, every 4th frame per LDS cycle, high side", 4);
   return 0;
 }
