@@ -17,6 +17,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // kind 0: v_mfma_f32_16x16x32_bf16   1: v_mfma_i32_16x16x64_i8   2: v_mfma_f32_16x16x4_f32   3: v_fma_f32 only (control)
 //      4: v_mfma_f32_32x32x16_bf16   5: v_mfma_i32_32x32x32_i8   6: v_mfma_f32_16x16x16_bf16 (64-bit operands)
 //      7: v_mfma_f32_16x16x32_f16    8: v_mfma_f32_16x16x32_fp8_fp8 (64-bit operands)   9: kind 0 with s_nop 7 between the MFMAs (half duty)
+//      10: v_mfma_i32_16x16x32_i8 (the older int8 opcode, 64-bit operands)
 template <int KIND>
 __global__ void __launch_bounds__(256) burst(volatile int *stop, float *sink, int prio, int max_loops) {
   const int lane = threadIdx.x & 63;
@@ -66,6 +67,10 @@ __global__ void __launch_bounds__(256) burst(volatile int *stop, float *sink, in
         const long la = ((long)ia.x << 32) | (unsigned)ia.y, lb = ((long)ib.x << 32) | (unsigned)ib.y;
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c1, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c3, 0, 0, 0);
+      } else if constexpr (KIND == 10) {
+        const long la = ((long)ia.x << 32) | (unsigned)ia.y, lb = ((long)ib.x << 32) | (unsigned)ib.y;
+        d0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, d2, 0, 0, 0); d3 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, d3, 0, 0, 0);
       } else if constexpr (KIND == 9) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1));
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0); asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1));
@@ -107,6 +112,7 @@ extern "C" int coburst_start(int kind, int blocks, int prio) {
     case 6: hipLaunchKernelGGL(burst<6>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
     case 7: hipLaunchKernelGGL(burst<7>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
     case 8: hipLaunchKernelGGL(burst<8>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
+    case 10: hipLaunchKernelGGL(burst<10>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
     case 9: hipLaunchKernelGGL(burst<9>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
     default: hipLaunchKernelGGL(burst<3>, dim3(blocks), dim3(256), 0, g_stream, dstop, g_sink, prio, 500000); break;
   }

@@ -15,7 +15,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int MT, int VT, int PM = 0, int PV = 0, bool SWAP = false>   // PM / PV: s_setprio of the MFMA / VALU waves; SWAP: MFMA role in the younger waves 4..7
-// MT: 0 none, 1 f32 16x16x4, 2 bf16 16x16x32, 3 i8 16x16x64, 4 f16 16x16x32, 5 f32 32x32x2 ; VT: 0 none, 1 v_fma_f32, 2 v_pk_fma_f32
+// MT: 0 none, 1 f32 16x16x4, 2 bf16 16x16x32, 3 i8 16x16x64, 4 f16 16x16x32, 5 f32 32x32x2, 6 bf16 16x16x16, 7 i8 16x16x32 (64-bit operands), 8 fp8 16x16x32 ; VT: 0 none, 1 v_fma_f32, 2 v_pk_fma_f32
 __global__ __launch_bounds__(512) void k(float *out, int nm, int nv, float a, float b) {
   extern __shared__ float lds[];
   const int wave = threadIdx.x >> 6;
@@ -75,6 +75,20 @@ __global__ __launch_bounds__(512) void k(float *out, int nm, int nv, float a, fl
         c3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c3, 0, 0, 0);
       }
       r = c0[0] + c1[1] + c2[2] + c3[3];
+    } else if constexpr (MT == 7 || MT == 8) {      // 64-bit operands: the older int8 16x16x32 and fp8 16x16x32
+      i4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+      f4 e0 = {0, 0, 0, 0}, e1 = e0, e2 = e0, e3 = e0;
+      const long x = ((long)threadIdx.x << 32) | 0x03050709, y = ((long)(int)(a * 100) << 32) | 0x01020304;
+      for (int i = 0; i < nm; i += 4) {
+        if constexpr (MT == 7) {
+          c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(x, y, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(x, y, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(x, y, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_i32_16x16x32_i8(x, y, c3, 0, 0, 0);
+        } else {
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(x, y, e0, 0, 0, 0); e1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(x, y, e1, 0, 0, 0);
+          e2 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(x, y, e2, 0, 0, 0); e3 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(x, y, e3, 0, 0, 0);
+        }
+      }
+      r = (float)(c0[0] + c1[1] + c2[2] + c3[3]) + e0[0] + e1[1] + e2[2] + e3[3];
     } else if constexpr (MT == 3) {
       i4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
       i4 x = {(int)threadIdx.x, 3, 5, 7}, y = {(int)(a * 100), 1, 2, 3};
@@ -147,5 +161,7 @@ int main() {
   pair<6>("bf16 16x16x16", d, 1 << 17, 8);
   pair<4>("f16 16x16x32", d, 1 << 17, 16);
   pair<3>("i8 16x16x64", d, 1 << 17, 16);
+  pair<7>("i8 16x16x32", d, 1 << 17, 16);
+  pair<8>("fp8 16x16x32", d, 1 << 17, 16);
   return 0;
 }
