@@ -31,7 +31,11 @@ def main():
                         rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)
     b = R.BatchDemod(cfg, a.streams, device=0)
     import bench
-    iq = bench.synth_fm_iq(torch, dev, a.streams, a.blocks * BL // 2, 2.4e6, True, 12345).view(a.streams, a.blocks, BL)
+    if a.data == "noise":
+        g = torch.Generator(device=dev); g.manual_seed(12345)
+        iq = torch.randint(0, 256, (a.streams, a.blocks, BL), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        iq = bench.synth_fm_iq(torch, dev, a.streams, a.blocks * BL // 2, 2.4e6, True, 12345).view(a.streams, a.blocks, BL)
     pcm = torch.zeros((a.streams, a.blocks, b.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((a.streams, a.blocks), dtype=torch.int32, device=dev)
     prof = torch.zeros((a.streams * 64, 16), dtype=torch.int64, device=dev)
