@@ -522,7 +522,9 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   kp.n_blocks = n_blocks;
   /* Cut each stream's tiles into time chunks until the grid offers enough
    * workers (wavefronts) per CU; each chunk > 0 replays warm_tiles tiles first
-   * (see the kernel), so keep chunks at least 8x longer than the replay. */
+   * (see the kernel), so keep chunks at least 4x longer than the replay.  (8x until round 3: a one-block launch of
+   * 256 streams then ran as four chunks per stream = ONE wave per SIMD, which takes 7 us per tile with nobody to hide its
+   * latencies under - 0.094 ms; eight chunks of 4 + 1 tiles, two waves per SIMD: profiles/r03y_blocks_per_launch.txt) */
   kp.n_streams = b->n_streams;
   kp.warm_tiles = fmdk_warm_tiles(&kp, b->cfg.math);
   kp.n_chunks = 1;
@@ -532,7 +534,13 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
     const long long m = kp.block_len >> 4, tile = fmdk_tile();
     const long long tiles = ((m + tile - 1) / tile) * n_blocks;
     long long want = ((long long)per_cu * b->n_cus + b->n_streams - 1) / b->n_streams;
-    const long long most = tiles / (8LL * kp.warm_tiles);
+    /* short launches: when three workers per SIMD would leave chunks under six replays' length, two per SIMD with longer
+     * chunks are faster (stereo, 2 blocks x 256 streams: 0.100 ms against 0.110) */
+    if (b->time_split == 0 && tiles < 6LL * kp.warm_tiles * want) {
+      const long long want2 = ((long long)(per_cu - per_cu / 3) * b->n_cus + b->n_streams - 1) / b->n_streams;
+      if (want2 < want) want = want2;
+    }
+    const long long most = tiles / (4LL * kp.warm_tiles);
     if (want > most) want = most;
     if (want > 1) kp.n_chunks = (int)want;
   }
