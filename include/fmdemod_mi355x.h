@@ -163,8 +163,9 @@ void fmd_demod_release(struct demod_state *d);
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
 #define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build (FMD_MATH_FAST_MFMA unless the
                              environment says FMD_MFMA=0).  The fast families want the device's CUs to themselves: a
-                             co-resident kernel that issues MFMAs with 128-bit operands (bf16 / f16 / int8 GEMMs on gfx950)
-                             was seen to corrupt their results; FMD_MATH_EXACT was not affected */
+                             kernel whose waves share their SIMDs and issue MFMAs with 128-bit operands (the bf16 / f16 / int8
+                             opcodes new in gfx950) was seen to corrupt their results - hipBLASLt's GEMMs beside them were not;
+                             FMD_MATH_EXACT was not affected */
 #define FMD_MATH_FAST_VALU 2   /* +-1 LSB, vector ALU only: fused multiply-adds in the reference's summation order */
 #define FMD_MATH_FAST_MFMA 3   /* +-1 LSB, matrix pipe beside the vector ALU: the /8 decimator as exact int8 products
                                   of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8) */
