@@ -343,6 +343,20 @@ def launch_ranks(args):
         raise SystemExit("bench.py: rank 0 printed no JSON line")
 
 
+def pick_device(local_rank, world, visible):
+    """Device index of this rank.  A launcher may give every rank ALL devices (index = LOCAL_RANK) or exactly ONE
+    (HIP_VISIBLE_DEVICES=k per rank, LOCAL_RANK=k still set): with fewer visible devices than LOCAL_RANK asks for and
+    several ranks running, the rank takes LOCAL_RANK modulo what it sees instead of giving up - the first case is
+    unchanged, the second binds device 0.  A single-rank run with an impossible LOCAL_RANK is still an error."""
+    if visible < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if local_rank < visible:
+        return local_rank
+    if world > 1:
+        return local_rank % visible
+    raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s)" % (local_rank, visible))
+
+
 def dry_run(args, rank, world):
     """The N-rank plumbing without a GPU (tests/test_bench_launcher.py): gloo, invented counters."""
     import torch
@@ -353,11 +367,18 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     first, count = shard_streams(args.streams * world, world, rank)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    n_vis = len([v for v in vis.split(",") if v.strip()]) if vis else int(os.environ.get("FMD_BENCH_DRYRUN_DEVICES", str(world)))
+    bound = pick_device(int(os.environ.get("LOCAL_RANK", "0")), world, n_vis)      # what the real run would set_device() to
     samples = count * args.blocks * (BLOCK_LEN // 2) * args.steps
     rep = gather_counters(dist if world > 1 else None, torch.device("cpu"), 1.0 + 0.25 * rank, samples,
                           1000 + rank, first)
+    devices = [bound]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, bound)
     if rank == 0:
-        print(json.dumps({"metric": "IQ Msamples/s through full_demod", "dry_run": True, "n_gpus": world,
+        print(json.dumps({"metric": "IQ Msamples/s through full_demod", "dry_run": True, "n_gpus": world, "bound_devices": devices,
                           "steps": args.steps, "warmup": args.warmup, "value": rep["samples"] / rep["elapsed_s"] / 1e6,
                           "unit": "Msamples/s", "scaling": "weak", "per_rank": rep["per_rank"]}), flush=True)
     if world > 1:
@@ -385,8 +406,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if local >= torch.cuda.device_count():
-        raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s)" % (local, torch.cuda.device_count()))
+    local = pick_device(local, world, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

@@ -90,3 +90,49 @@ def test_failing_rank_fails_the_launch():
 def test_gpus_below_one_is_rejected():
     r = _run(["--gpus", "0", "--dry-run"])
     assert r.returncode != 0
+
+
+def _ranks_by_hand(world, env_of_rank):
+    """What torch.distributed.run (or a scheduler) does: one process per rank with RANK / LOCAL_RANK / WORLD_SIZE set."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = []
+    for k in range(world):
+        e = dict(os.environ)
+        e.update({"RANK": str(k), "LOCAL_RANK": str(k), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
+        e.update(env_of_rank(k))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", str(world), "--steps", "1", "--warmup", "0", "--dry-run"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, [o[1][-400:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_one_visible_device_per_rank_binds_device_zero():
+    """A launcher that narrows every rank to ONE visible device (HIP_VISIBLE_DEVICES=k) still sets LOCAL_RANK=k: ranks 1..N-1
+    must bind the device they see (index 0), not exit because LOCAL_RANK >= device count."""
+    out = _ranks_by_hand(2, lambda k: {"HIP_VISIBLE_DEVICES": str(k)})
+    assert out["bound_devices"] == [0, 0] and out["n_gpus"] == 2
+    assert [p["checksum"] for p in out["per_rank"]] == [0, 256]          # the stream shards do not depend on the binding
+
+
+def test_all_devices_visible_binds_local_rank():
+    out = _ranks_by_hand(2, lambda k: {"HIP_VISIBLE_DEVICES": "0,1"})
+    assert out["bound_devices"] == [0, 1]
+
+
+def test_pick_device_rules():
+    sys.path.insert(0, ROOT)
+    import bench
+    import pytest
+    assert bench.pick_device(3, 8, 8) == 3
+    assert bench.pick_device(3, 8, 1) == 0
+    assert bench.pick_device(5, 8, 4) == 1          # two ranks per visible device: still a device that exists
+    with pytest.raises(SystemExit):
+        bench.pick_device(1, 1, 1)                  # a single rank asking for a device that is not there
+    with pytest.raises(SystemExit):
+        bench.pick_device(0, 2, 0)
