@@ -251,6 +251,25 @@ static int build_a_tab(const fmd_taps *t, int offset_tuning, fmdk_params *k) {  
   return 0;
 }
 
+/* Matrix-pipe form of stage C (fmd_kernels.inc, mpx_tile_i8): per filter the largest qf that keeps round(h 2^qf) inside three balanced
+ * int8 limbs (-8 421 504 .. 8 355 711), and the scale that puts the integer sums together.  -1: not the 90-tap stereo kind, or a
+ * filter is all zero. */
+static int build_ci_scales(const fmd_taps *t, int size, fmdk_params *k) {
+  if (size != 90) return -1;
+  const float *taps[3] = {t->fm, t->fp, t->fs};
+  for (int f = 0; f < 3; f++) {
+    double mx = 0.0;
+    for (int u = 0; u < 45; u++) mx = fmax(mx, fabs((double)taps[f][u]));
+    if (!(mx > 0.0) || !isfinite(mx)) return -1;
+    int qf = 40;
+    while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
+    if (qf < 8) return -1;                                  /* taps of magnitude 2^15: not a filter this form was made for */
+    k->ci_qf[f] = qf;
+    k->ci_scale[f] = (float)ldexp(1.0, 32 - 20 - qf);
+  }
+  return 0;
+}
+
 static void fill_params(fmd_batch *b) {
   fmdk_params *k = &b->kp;
   const fmd_config *c = &b->cfg;
@@ -409,7 +428,8 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   /* FMD_MATH_FAST = the faster of the two +-1 LSB kernel families: the matrix-pipe one, unless FMD_MFMA=0 */
   if (b->cfg.math == FMD_MATH_FAST) {
     const char *e_m = getenv("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 1;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C */
+    const int sel = e_m ? atoi(e_m) : 2;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2 (default): stages A and C
+                                                     (90-tap stereo with whole tiles; everything else runs 1, see below) */
     b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : FMD_MATH_FAST_MFMA;
   }
   b->n_streams = n_streams;
@@ -418,6 +438,13 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   else if ((rc = fmd_design_taps(cfg, &b->taps))) { free(b); return rc; }
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
+  if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {
+    /* stage C on the matrix pipe: 90-tap stereo with whole tiles (block_len a multiple of 8192 bytes); anything else runs the
+     * stage-A-only family, also when the caller named this one (it is a speed choice inside one +-1 LSB contract) */
+    if (!(b->cfg.mode == 2 && b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0 &&
+          build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0))
+      b->cfg.math = FMD_MATH_FAST_MFMA;
+  }
   if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {

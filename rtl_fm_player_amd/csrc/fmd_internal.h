@@ -61,6 +61,11 @@ typedef struct fmdk_params {
    * d = 4 s + g - r, zero outside 0..3 (fmd_host.c, build_a_tab). */
   int32_t a_tab[3 * 2 * 4 * 4];
   float a_bias_i, a_bias_q;          /* 2^-34 * sum of E over the window: the (u - 127.5) offset of the reference's table */
+  /* matrix-pipe form of stage C (FMD_MATH_FAST_MFMA_C, 90-tap stereo): taps of filter f (fm, fp, fs) as T = round(h 2^qf) in three
+   * balanced int8 limbs (the kernel builds its byte tables from fm / fp / fs and qf), samples as round(v 2^20):
+   * y = ci_scale[f] (A0 + A1 2^-8 + A2 2^-16 + A3 2^-24), ci_scale = 2^(32 - 20 - qf)  (fmd_kernels.inc, mpx_tile_i8) */
+  int32_t ci_qf[3];
+  float ci_scale[3];
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a
