@@ -37,3 +37,20 @@ def test_kernels_hold_no_forbidden_packed_form(kind):
     errors = [f for f in found if f[1] == "error"]
     assert not errors, "%d instructions of the forbidden form, first: line %d: %s (%s)" % (
         len(errors), errors[0][0], errors[0][2], errors[0][3])
+
+
+@pytest.mark.parametrize("kind", ["fast", "mfma", "exact"])
+def test_kernels_have_no_scratch_and_no_spills(kind):
+    """The tile loop must not touch scratch (a scratch reload waits on vmcnt and drains the IQ words in flight, DESIGN.md
+    section 3) - cold paths included: a change that pushes any instantiation over its register budget fails here."""
+    import re
+    text = open(isa_lint.device_asm(kind)).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    names = re.findall(r"\.name:\s+(\S+)", meta)
+    scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", meta)]
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", meta)]
+    sspills = [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", meta)]
+    assert names and len(scratch) == len(names) == len(spills)
+    bad = [(n, sc, sp) for n, sc, sp in zip(names, scratch, spills) if sc or sp]
+    assert not bad, "kernels with scratch / VGPR spills: %s" % bad
+    assert len(sspills) == len(names)

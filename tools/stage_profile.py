@@ -57,7 +57,9 @@ def main():
     out = {"kernel_ms_min": round(min(ms), 4), "kernel_ms_median": round(float(np.median(ms)), 4), "kernel_ms_with_stamps": round(ms_prof, 4),
            "Gsamples_per_s": round(samples / (min(ms) * 1e-3) / 1e9, 1),
            "cycles_total_mean": tot, "clock_GHz_est": round(tot / (ms_prof * 1e-3) / 1e9, 3),
-           "share": {n: round(float(p[:, i].mean() / tot), 4) for i, n in enumerate(NAMES)}}
+           "share": {n: round(float(p[:, i].mean() / tot), 4) for i, n in enumerate(NAMES)},
+           "redo_prof(-DFMD_REDO_PROF builds: count, cycles step1, step2, step3, rest; per worker)": [round(float(p[:, 10 + i].mean()), 1) for i in range(5)],
+           "workers": int(p.shape[0])}
     print(json.dumps(out))
 
 
