@@ -80,6 +80,9 @@ int fmd_device_count(void) {
 /* Environment knobs that change the arithmetic thresholds or the kernels' shape exist only in tuning builds
  * (make EXTRA_CFLAGS=-DFMD_TUNING): the shipped library reads FMD_MFMA (kernel family behind FMD_MATH_FAST) and
  * FMD_MATH_FAST (drop-in surface) and nothing else. */
+#ifndef FMD_CARRIER_L2_DEFAULT
+#define FMD_CARRIER_L2_DEFAULT 0.5f     /* measured: 0.125 fails 4 of the noise / hand-over tests, 0.25 and up none (r04x); 1: always the full redo */
+#endif
 static const char *tuning_env(const char *name) {
 #ifdef FMD_TUNING
   return getenv(name);
@@ -351,6 +354,15 @@ static void fill_params(fmd_batch *b) {
     const char *es = tuning_env("FMD_CARRIER_SCALE");   /* ... or scale the derived K */
     if (es) K *= (float)atof(es);
     k->car_inv_k2 = K > 0.f ? 1.0f / (K * K) : 3.0e38f;
+    /* Two levels (round 4).  A flagged sample first gets its pilot / L-R sums again from the worker's own window, in the
+     * reference's ORDER of operations: that removes the order-of-summation part of the difference to the reference (what is left:
+     * the window's samples are a few ulps off each, and roundings that fall differently because of it).  Only samples within
+     * L K of the origin after that are recomputed from the IQ words.  L was measured like K (tools/fuzz_parity.py and the noise /
+     * hand-over tests with FMD_CARRIER_L2 in a tuning build, profiles/r04w_carrier_l2.txt). */
+    float L2 = FMD_CARRIER_L2_DEFAULT;
+    const char *el = tuning_env("FMD_CARRIER_L2");
+    if (el) L2 = (float)atof(el);
+    k->car_inv_k2_l2 = (K > 0.f && L2 > 0.f) ? 1.0f / (K * L2 * K * L2) : (L2 > 0.f ? 3.0e38f : 0.f);
   }
   k->size = c->size;
   k->half = c->size >> 1;
