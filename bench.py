@@ -343,6 +343,86 @@ def launch_ranks(args):
         raise SystemExit("bench.py: rank 0 printed no JSON line")
 
 
+def single_stream_leg(R, mode_kw, math_code, n_blocks=64):
+    """BASELINE configs[1]: ONE 2.4 Msps stream, one reference block (262144 B = 54.6 ms of signal) per call - the operating
+    point of the reference's demod thread (src/rtl_fm_player.c:855-933).  Milliseconds per block through
+      (a) the reference-shaped surface: rotate_90_u8_f32(d) + full_demod(d) on a struct demod_state (host buffers in and out);
+      (b) fmd_batch_run_host with 1 stream x 1 block;
+      (c) the reference's own rotate_90_u8_f32 + full_demod on one host core (oracle/_ref/libref.so; the oracle port where the
+          compiled reference did not travel), same blocks.
+    Never `value`: a latency figure for the drop-in surface, host copies included."""
+    import ctypes as C
+    from oracle import lcg_bytes
+    L = R.lib()
+    iq = lcg_bytes(n_blocks * BLOCK_LEN, 777)[0].reshape(n_blocks, BLOCK_LEN)
+    out = {"blocks": n_blocks, "block_bytes": BLOCK_LEN, "signal_ms_per_block": round(BLOCK_LEN / 2 / 2.4e6 * 1e3, 2)}
+    # (a) reference-shaped calls
+    prev_env = os.environ.get("FMD_MATH_FAST")
+    if math_code != R.MATH_EXACT:
+        os.environ["FMD_MATH_FAST"] = "1"
+    d = R.DemodState()
+    L.demod_init(C.byref(d))
+    d.rate_in = d.rate_out = mode_kw["rate_in"]
+    d.rate_out2 = mode_kw["rate_out2"]
+    d.lpr.mode = mode_kw["mode"]
+    d.lpr.size = 90 if mode_kw["mode"] == 2 else 128
+    d.deemph_lambda = float(L.fmd_deemph_lambda(mode_kw["rate_out2"], 50e-6))
+    L.init_u8_f32_table(); L.init_lp_f32(); L.init_lp_real_f32(C.byref(d))
+    d.buf_len = BLOCK_LEN
+    lens_a = []
+
+    def call(k):
+        C.memmove(d.buf, iq[k].ctypes.data, BLOCK_LEN)
+        L.rotate_90_u8_f32(C.byref(d))
+        L.full_demod(C.byref(d))
+        lens_a.append(d.result_len)
+
+    for k in range(4):
+        call(k)                                        # builds the batch, settles allocations
+    t0 = time.perf_counter()
+    for k in range(4, n_blocks):
+        call(k)
+    out["dropin_ms_per_block"] = round((time.perf_counter() - t0) / (n_blocks - 4) * 1e3, 4)
+    pcm_tail = np.ctypeslib.as_array(d.result)[:d.result_len].copy()
+    L.deinit_lp_real_f32(C.byref(d))
+    if prev_env is None:
+        os.environ.pop("FMD_MATH_FAST", None)
+    # (b) batch API, one stream, one block per call
+    b = R.BatchDemod(R.wbfm_config(block_len=BLOCK_LEN, math=math_code, **mode_kw), 1)
+    for k in range(4):
+        b.run_host(iq[k:k + 1], 1)
+    t0 = time.perf_counter()
+    for k in range(4, n_blocks):
+        pcm_b, lens_b = b.run_host(iq[k:k + 1], 1)
+    out["batch_run_host_ms_per_block"] = round((time.perf_counter() - t0) / (n_blocks - 4) * 1e3, 4)
+    b.close()
+    # (c) the reference on one host core
+    kind, cls = "port", None
+    try:
+        from oracle import refbind
+        if refbind.have_ref():
+            kind, cls = "reference", refbind.RefStream
+    except ImportError:
+        pass
+    if cls is None:
+        from oracle import OracleStream as cls
+    o = cls(**mode_kw)
+    o.run(iq[:4].reshape(-1), BLOCK_LEN)
+    t0 = time.perf_counter()
+    want, wl = o.run(iq[4:].reshape(-1), BLOCK_LEN)
+    out["cpu_ms_per_block"] = round((time.perf_counter() - t0) / (n_blocks - 4) * 1e3, 4)
+    out["cpu_kind"] = kind
+    # the last block of (a) and (b) against (c): the drop-in really demodulated the stream
+    tail = want[-int(wl[-1]):]
+    tol = 0 if math_code == R.MATH_EXACT else 1
+    da = int(np.abs(pcm_tail.astype(np.int32) - tail.astype(np.int32)).max()) if pcm_tail.size == tail.size else 1 << 20
+    db = int(np.abs(pcm_b[0, 0, :lens_b[0, 0]].astype(np.int32) - tail.astype(np.int32)).max()) if lens_b[0, 0] == tail.size else 1 << 20
+    out["parity_last_block_lsb"] = {"dropin": da, "batch": db, "tolerance": tol}
+    assert da <= tol and db <= tol, "single-stream leg: PCM differs from the CPU path (%d / %d LSB)" % (da, db)
+    out["dropin_vs_cpu"] = round(out["cpu_ms_per_block"] / out["dropin_ms_per_block"], 2)
+    return out
+
+
 def pick_device(local_rank, world, visible):
     """Device index of this rank.  A launcher may give every rank ALL devices (index = LOCAL_RANK) or exactly ONE
     (HIP_VISIBLE_DEVICES=k per rank, LOCAL_RANK=k still set): with fewer visible devices than LOCAL_RANK asks for and
@@ -579,7 +659,7 @@ def main():
                 "kernel_family": {R.MATH_EXACT: "exact", R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma",
                                   R.MATH_FAST_MFMA_C: "fast-mfma-c"}.get(batch.math, str(batch.math)),
                 "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C),
-                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (f32 MPX filters)"}.get(batch.math, "none"),
+                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (i8 MPX filters)"}.get(batch.math, "none"),
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
                 "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },
@@ -620,6 +700,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds, iq)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
+        if not args.no_extra and world == 1:
+            out["single_stream"] = single_stream_leg(R, cfg_kw, math_code)
         if not args.no_e2e and world == 1:
             out["e2e_h2d"] = e2e_h2d(args.mode, min(args.e2e_streams, S), B, args.e2e_jobs, args.math)
         print(json.dumps(out), flush=True)

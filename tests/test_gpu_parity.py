@@ -250,6 +250,61 @@ def test_drop_in_full_demod(R, lcg40):
     L.deinit_lp_real_f32(C.byref(d))
 
 
+def test_drop_in_notices_a_caller_who_edits_the_struct(R, lcg40):
+    """The drop-in keeps the carried state on the device between calls (one synchronisation per block) and skips the upload
+    while the struct still holds what the last call mirrored into it.  The reference's state IS the struct, though
+    (src/rtl_fm_player.c:758-788 reads and writes its fields), so a caller may reset or restore it between blocks: the next
+    call must see the struct's values.  Two blocks, then the struct's state is zeroed like a fresh stream's: block 3 must
+    equal the oracle's first block of a new stream on that input - and a restore of a saved state must continue where it was."""
+    import copy
+    from oracle import OracleStream
+    from rtl_fm_player_amd.capi import DemodState
+    L = R.lib()
+    d = DemodState()
+    L.demod_init(C.byref(d))
+    d.rate_in = d.rate_out = 300000
+    d.rate_out2 = 48000
+    d.deemph_lambda = L.fmd_deemph_lambda(48000, 50e-6)
+    L.init_u8_f32_table(); L.init_lp_f32(); L.init_lp_real_f32(C.byref(d))
+
+    def block(k):
+        blk = lcg40[k * BL:(k + 1) * BL]
+        C.memmove(d.buf, blk.ctypes.data, BL)
+        d.buf_len = BL
+        L.rotate_90_u8_f32(C.byref(d))
+        L.full_demod(C.byref(d))
+        return np.frombuffer(d.result, dtype=np.int16, count=d.result_len).copy()
+
+    s = OracleStream(**CONFIGS["stereo_300k"])
+    for k in range(2):
+        assert np.array_equal(block(k), s.block(lcg40[k * BL:(k + 1) * BL]))
+    # save what the struct holds after block 1 (the scalars and the three rings)
+    saved = dict(tb=list(d.lowpass_tb), pre=(d.pre_r_f32, d.pre_j_f32), de=(d.deemph_l_f32, d.deemph_r_f32), acc=d.prev_lpr_index,
+                 pp=d.lpr.pp, pos=d.lpr.pos, br=[d.lpr.br[i] for i in range(90)], bm=[d.lpr.bm[i] for i in range(90)],
+                 bs=[d.lpr.bs[i] for i in range(90)])
+    # a fresh stream's state, written by the caller
+    for i in range(48): d.lowpass_tb[i] = 0.0
+    d.pre_r_f32 = d.pre_j_f32 = d.deemph_l_f32 = d.deemph_r_f32 = 0.0
+    d.prev_lpr_index = 0
+    d.lpr.pp = 0.0
+    d.lpr.pos = 0
+    for i in range(90): d.lpr.br[i] = d.lpr.bm[i] = d.lpr.bs[i] = 0.0
+    fresh = OracleStream(**CONFIGS["stereo_300k"])
+    assert np.array_equal(block(2), fresh.block(lcg40[2 * BL:3 * BL])), "the zeroed struct was not uploaded"
+    # restore the saved state: block 2 again, now as the continuation of blocks 0, 1
+    for i in range(48): d.lowpass_tb[i] = saved["tb"][i]
+    d.pre_r_f32, d.pre_j_f32 = saved["pre"]
+    d.deemph_l_f32, d.deemph_r_f32 = saved["de"]
+    d.prev_lpr_index = saved["acc"]
+    d.lpr.pp = saved["pp"]
+    d.lpr.pos = saved["pos"]
+    for i in range(90):
+        d.lpr.br[i] = saved["br"][i]; d.lpr.bm[i] = saved["bm"][i]; d.lpr.bs[i] = saved["bs"][i]
+    assert np.array_equal(block(2), s.block(lcg40[2 * BL:3 * BL])), "the restored struct was not uploaded"
+    assert np.array_equal(block(3), s.block(lcg40[3 * BL:4 * BL]))          # and on from there without an upload
+    L.deinit_lp_real_f32(C.byref(d))
+
+
 def test_ingest_callback_and_pump(R):
     """rtlsdr_read_async-shaped ingest: odd-sized callback buffers -> pinned ring -> batch."""
     from oracle import OracleStream, lcg_bytes
