@@ -575,7 +575,7 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
     long long want = ((long long)per_cu * b->n_cus + b->n_streams - 1) / b->n_streams;
     /* short launches: when three workers per SIMD would leave chunks under six replays' length, two per SIMD with longer
      * chunks are faster (stereo, 2 blocks x 256 streams: 0.100 ms against 0.110) */
-    if (b->time_split == 0 && tiles < 6LL * kp.warm_tiles * want) {
+    if (b->time_split == 0 && per_cu >= 12 && tiles < 6LL * kp.warm_tiles * want) {   /* (kernels budgeted for two per SIMD already are) */
       const long long want2 = ((long long)(per_cu - per_cu / 3) * b->n_cus + b->n_streams - 1) / b->n_streams;
       if (want2 < want) want = want2;
     }
