@@ -186,7 +186,7 @@ def cpu_baseline(cfg_kw, seconds, iq_dev=None):
     }
 
 
-def e2e_h2d(mode, n_streams, n_blocks, n_jobs, math_name):
+def e2e_h2d(mode, n_streams, n_blocks, n_jobs, math_code, cfg_kw):
     """IQ that starts in HOST memory, measured without Python in the loop: rtl_fm_player_amd/fmd_e2e_bench (C, csrc/
     fmd_e2e_bench.c) runs as a child process - feeder pthreads in the dongle threads' role call fmd_ingest_callback one
     262144-byte transfer at a time (src/rtl_fm_player.c:790-837), its main thread is the demod thread (:855-933):
@@ -196,8 +196,9 @@ def e2e_h2d(mode, n_streams, n_blocks, n_jobs, math_name):
     if not os.path.isfile(exe):
         raise RuntimeError("rtl_fm_player_amd/fmd_e2e_bench not built (python -c 'import __graft_entry__ as g; g.build()')")
     n_thr = max(1, min(usable_cores(), n_streams, 16))
+    # the tool runs exactly the bench's configuration and kernel family, and says so in its line ("config")
     cmd = [exe, "-S", str(n_streams), "-B", str(n_blocks), "-J", str(max(2, n_jobs)), "-T", str(n_thr),
-           "-m", "1" if mode in ("mono", "nfm") else "2"] + (["-e"] if math_name == "exact" else [])
+           "-m", str(cfg_kw["mode"]), "-i", str(cfg_kw["rate_in"]), "-o", str(cfg_kw["rate_out2"]), "-M", str(int(math_code))]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("fmd_e2e_bench failed: " + r.stderr[-500:])
@@ -703,7 +704,7 @@ def main():
         if not args.no_extra and world == 1:
             out["single_stream"] = single_stream_leg(R, cfg_kw, math_code)
         if not args.no_e2e and world == 1:
-            out["e2e_h2d"] = e2e_h2d(args.mode, min(args.e2e_streams, S), B, args.e2e_jobs, args.math)
+            out["e2e_h2d"] = e2e_h2d(args.mode, min(args.e2e_streams, S), B, args.e2e_jobs, math_code, cfg_kw)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

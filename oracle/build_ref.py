@@ -51,6 +51,7 @@ HEADER_RANGES = [
 ]
 HOT_PATH = [(SRC, 195, 788)]
 
+RING_HEADERS = ("rtl-sdr.h", "rtl-sdr_export.h")   # included by the ring library as they lie in the reference tree
 RING_RANGES = [
     (HDR, 30, 46),
     (HDR, 56, 57),     # _beverbose, _do_exit
@@ -147,7 +148,14 @@ def ref_status():
     pin = load_pin()
     ok = bool(meta.get("pinned")) and pin is not None and pin.get("slices_sha256") == meta.get("slices_sha256") \
         and actual == meta.get("so_sha256")
-    return dict(meta, pinned=ok, so_sha256_on_disk=actual)
+    try:
+        with open(ref_paths()[1], "rb") as f:
+            ring_actual = hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        ring_actual = None
+    ring_ok = bool(meta.get("ring_pinned")) and pin is not None and pin.get("ring_sha256") == meta.get("ring_sha256") \
+        and ring_actual is not None and ring_actual == meta.get("ring_so_sha256")
+    return dict(meta, pinned=ok, so_sha256_on_disk=actual, ring_pinned=ring_ok, ring_so_sha256_on_disk=ring_actual)
 
 
 def reference_present():
@@ -178,8 +186,10 @@ def build_ref(force=False, quiet=False):
     stamp = shim_stamp.hexdigest()
     if not force and os.path.isfile(so) and os.path.isfile(ring) and os.path.isfile(stamp_file):
         with open(stamp_file) as f:
-            if f.read().strip() == stamp:
-                return True
+            same = f.read().strip() == stamp
+        st = ref_status() if same else None           # sources unchanged AND both libraries on disk are the ones recorded then
+        if st is not None and st.get("so_sha256_on_disk") == st.get("so_sha256") and st.get("ring_so_sha256_on_disk") == st.get("ring_so_sha256"):
+            return True
     head = ["#include <%s>" % h for h in LIBC]
     hot = _slice(HEADER_RANGES) + _slice(HOT_PATH)
     # Pin: the text handed to gcc is untrusted input that becomes a library this process loads.  Its hash (the sliced
@@ -194,13 +204,28 @@ def build_ref(force=False, quiet=False):
                          "(FMD_REFERENCE_UNPINNED=1 builds an unpinned library)" % (sliced, pin and pin.get("slices_sha256")))
     text = "\n".join(head + hot + _shim("ref_shim.c")) + "\n"
     _compile(text, so)
+    # the ring library (rtlsdr_callback, :790-837) is built from the same untrusted tree and loaded by the tests: its sliced lines
+    # and the bytes of the two reference headers it includes are pinned the same way ("ring_sha256")
+    ring_lines = _slice(RING_RANGES)
+    ring_hash = hashlib.sha256("\n".join(l for l in ring_lines if not l.startswith("#line ")).encode())
+    for h in RING_HEADERS:
+        with open(os.path.join(REF, "include", h), "rb") as f:
+            ring_hash.update(f.read())
+    ring_sliced = ring_hash.hexdigest()
+    ring_pinned = pin is not None and pin.get("ring_sha256") == ring_sliced
+    if not ring_pinned and not os.environ.get("FMD_REFERENCE_UNPINNED"):
+        raise SystemExit("build_ref: the reference's ring lines / headers hash to %s, oracle/ref_pin.json says %s - not building "
+                         "(FMD_REFERENCE_UNPINNED=1 builds an unpinned library)" % (ring_sliced, pin and pin.get("ring_sha256")))
     ring_head = head + ['#include "%s"' % os.path.join(REF, "include", "rtl-sdr.h")]
-    text = "\n".join(ring_head + _slice(RING_RANGES) + _shim("ref_ring_shim.c")) + "\n"
+    text = "\n".join(ring_head + ring_lines + _shim("ref_ring_shim.c")) + "\n"
     _compile(text, ring, extra=["-I" + os.path.join(REF, "include")])   # rtl-sdr.h includes <rtl-sdr_export.h>
     with open(so, "rb") as f:
         so_hash = hashlib.sha256(f.read()).hexdigest()
+    with open(ring, "rb") as f:
+        ring_so_hash = hashlib.sha256(f.read()).hexdigest()
     with open(os.path.join(OUT, "libref.meta.json"), "w") as f:
-        json.dump({"slices_sha256": sliced, "so_sha256": so_hash, "pinned": pinned}, f)
+        json.dump({"slices_sha256": sliced, "so_sha256": so_hash, "pinned": pinned,
+                   "ring_sha256": ring_sliced, "ring_so_sha256": ring_so_hash, "ring_pinned": ring_pinned}, f)
     with open(stamp_file, "w") as f:
         f.write(stamp + "\n")
     if not quiet:

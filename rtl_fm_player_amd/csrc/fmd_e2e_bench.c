@@ -11,7 +11,8 @@
  * plain memcpy of the same transfers into pinned memory and into ordinary memory.
  *
  *   fmd_e2e_bench [-S streams=64] [-B blocks per job=16] [-J jobs=20] [-T feeder threads=16] [-m mode 2|1] [-e]
- * prints ONE JSON line on stdout.
+ *                 [-i rate_in=300000] [-o rate_out2=48000] [-z lpr.size] [-M math code 0..4 (fmdemod_mi355x.h)] [-W stall seconds=60]
+ * prints ONE JSON line on stdout (the configuration it really ran is part of it).
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -48,9 +49,11 @@ typedef struct {
 
 static void *feeder(void *arg) {
   feeder_t *f = (feeder_t *)arg;
-  long long done[1024];
-  int mine[1024], n_mine = 0;
-  for (int s = f->tid; s < f->n_streams && n_mine < 1024; s += f->n_thr) { mine[n_mine] = s; done[n_mine++] = 0; }
+  const int cap = (f->n_streams + f->n_thr - 1) / f->n_thr;      /* every stream has a feeder, whatever S and T are */
+  long long *done = (long long *)calloc((size_t)cap, sizeof(*done));
+  int *mine = (int *)calloc((size_t)cap, sizeof(*mine)), n_mine = 0;
+  if (!done || !mine) { atomic_store(f->stop, 1); free(done); free(mine); return NULL; }
+  for (int s = f->tid; s < f->n_streams; s += f->n_thr) { mine[n_mine] = s; done[n_mine++] = 0; }
   int left = n_mine;
   while (left > 0 && !atomic_load(f->stop)) {
     int progressed = 0;
@@ -67,6 +70,7 @@ static void *feeder(void *arg) {
     }
     if (!progressed) sched_yield();
   }
+  free(done); free(mine);
   return NULL;
 }
 
@@ -95,7 +99,9 @@ static double copy_rate(int n_thr, uint8_t **dst, uint8_t **src, size_t bytes, i
 
 int main(int argc, char **argv) {
   int S = 64, B = 16, J = 20, T = 16, mode = 2, exact = 0, opt;
-  while ((opt = getopt(argc, argv, "S:B:J:T:m:eh")) != -1) {
+  int rate_in = 300000, rate_out2 = 48000, fsize = 0, math = -1;
+  double stall_s = 60.0;
+  while ((opt = getopt(argc, argv, "S:B:J:T:m:ei:o:z:M:W:h")) != -1) {
     switch (opt) {
       case 'S': S = atoi(optarg); break;
       case 'B': B = atoi(optarg); break;
@@ -103,13 +109,20 @@ int main(int argc, char **argv) {
       case 'T': T = atoi(optarg); break;
       case 'm': mode = atoi(optarg); break;
       case 'e': exact = 1; break;
+      case 'i': rate_in = atoi(optarg); break;
+      case 'o': rate_out2 = atoi(optarg); break;
+      case 'z': fsize = atoi(optarg); break;
+      case 'M': math = atoi(optarg); break;
+      case 'W': stall_s = atof(optarg); break;
       default: fprintf(stderr, "usage: fmd_e2e_bench [-S streams] [-B blocks/job] [-J jobs] [-T feeder threads] [-m mode] [-e]\n"); return opt == 'h' ? 0 : 2;
     }
   }
   if (S < 1 || S > 16384 || B < 1 || J < 2 || T < 1 || T > 256) { fprintf(stderr, "fmd_e2e_bench: bad arguments\n"); return 2; }
   if (T > S) T = S;
-  fmd_config cfg = {300000, 300000, 48000, mode, mode == 1 ? 128 : 90, 1, 0, 0.f, 0.4f, BL, exact ? FMD_MATH_EXACT : FMD_MATH_FAST};
-  cfg.deemph_lambda = fmd_deemph_lambda(48000, 50e-6);
+  if (fsize <= 0) fsize = mode == 1 ? 128 : 90;
+  if (math < 0) math = exact ? FMD_MATH_EXACT : FMD_MATH_FAST;
+  fmd_config cfg = {rate_in, rate_in, rate_out2, mode, fsize, 1, 0, 0.f, 0.4f, BL, math};
+  cfg.deemph_lambda = fmd_deemph_lambda(rate_out2 > 0 ? rate_out2 : rate_in, 50e-6);
   fmd_batch *b = NULL;
   if (fmd_batch_create(&b, &cfg, NULL, S, -1)) { fprintf(stderr, "fmd_e2e_bench: %s\n", fmd_last_error()); return 1; }
   const int stride = fmd_batch_pcm_stride(b);
@@ -137,9 +150,14 @@ int main(int argc, char **argv) {
   }
   /* the demod thread: a job starts when every stream has B blocks buffered (:863-868 polls the same way) */
   int begun = 0, ended = 0, rc = 0;
-  double t0 = 0, kernel_wait = 0;
+  double t0 = 0, kernel_wait = 0, last_progress = now_s();
   unsigned long long pcm_values = 0;
   while (ended < J + 2) {
+    if (atomic_load(&stop) || now_s() - last_progress > stall_s) {   /* a feeder gave up, or nothing has moved for stall_s seconds */
+      fprintf(stderr, "fmd_e2e_bench: stalled (%d jobs begun, %d ended)\n", begun, ended);
+      atomic_store(&stop, 1);
+      break;
+    }
     if (begun < J + 2 && begun - ended < 2) {
       int ready = 1;
       for (int s = 0; s < S && ready; s++) ready = fmd_ingest_buffered(rings[s]) >= (uint32_t)B * BL;
@@ -147,6 +165,7 @@ int main(int argc, char **argv) {
         rc = fmd_batch_pump_begin(b, B);
         if (rc != B) { fprintf(stderr, "fmd_e2e_bench: pump_begin -> %d %s\n", rc, fmd_last_error()); atomic_store(&stop, 1); break; }
         begun++;
+        last_progress = now_s();
         continue;
       }
       if (begun == ended) { sched_yield(); continue; }          /* nothing in flight: wait for the feeders */
@@ -156,6 +175,7 @@ int main(int argc, char **argv) {
     kernel_wait += now_s() - w0;
     if (rc != B) { fprintf(stderr, "fmd_e2e_bench: pump_end -> %d %s\n", rc, fmd_last_error()); atomic_store(&stop, 1); break; }
     ended++;
+    last_progress = now_s();
     if (ended == 2) { t0 = now_s(); kernel_wait = 0; }
     if (ended > 2) for (int i = 0; i < S * B; i++) pcm_values += (unsigned long long)lens[i];
   }
@@ -185,13 +205,14 @@ int main(int argc, char **argv) {
   cpu_set_t set;
   int affinity = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : -1;
 
-  printf("{\"value\": %.1f, \"unit\": \"Msamples/s\", \"pcie_gbs\": %.2f, \"streams\": %d, \"blocks_per_job\": %d, \"jobs\": %d, "
+  printf("{\"value\": %.1f, \"unit\": \"Msamples/s\", \"pcie_gbs\": %.2f, \"config\": {\"rate_in\": %d, \"rate_out2\": %d, \"mode\": %d, \"size\": %d, "
+         "\"math_requested\": %d, \"math_run\": %d}, \"streams\": %d, \"blocks_per_job\": %d, \"jobs\": %d, "
          "\"feeder_threads\": %d, \"ms_per_job\": %.3f, \"pcm_values\": %llu, \"callback_gbs_per_thread\": %.2f, "
          "\"demod_thread_wait_s\": %.3f, \"memcpy_gbs\": {\"threads_to_pinned\": %.2f, \"threads_to_pageable\": %.2f, \"one_thread_to_pageable\": %.2f}, "
          "\"cpus_online\": %ld, \"cpus_in_affinity_mask\": %d, "
          "\"path\": \"C, no Python: %d pthreads call fmd_ingest_callback (262144-byte transfers from pageable memory) -> pinned rings "
          "(2 jobs deep) -> H2D straight from the rings, fmd_batch_pump_begin/_end with two jobs in flight -> PCM in host memory; wall clock\"}\n",
-         nbytes / 2 / dt / 1e6, nbytes / dt / 1e9, S, B, J, T, dt / J * 1e3, pcm_values, nbytes / busy / 1e9 , kernel_wait, cp_pin, cp_pag, cp_one,
+         nbytes / 2 / dt / 1e6, nbytes / dt / 1e9, rate_in, rate_out2, mode, fsize, math, fmd_batch_math(b), S, B, J, T, dt / J * 1e3, pcm_values, nbytes / busy / 1e9 , kernel_wait, cp_pin, cp_pag, cp_one,
          ncpu, affinity, T);
   for (int s = 0; s < S; s++) { fmd_ingest_destroy(rings[s]); free(src[s]); }
   fmd_batch_destroy(b);

@@ -1274,13 +1274,19 @@ int fmd_batch_pump_begin(fmd_batch *b, int max_blocks) {
      * (they are still in the rings, so the next call sees them again); a part an overflow has meanwhile released
      * (moved from inflight to debt) is not taken back a second time */
     hipStreamSynchronize(b->copy_stream);
+    /* debt = bytes an overflow has eaten from the OLDEST end of the in-flight region: they belong to the other job first
+     * (if one still holds ring space), and only what exceeds that job's take was eaten from this one.  That part is already
+     * released (rpos and size moved on when the overflow happened); the rest of this job's take goes back to "buffered",
+     * and the other job's share of the debt stays for its own release. */
+    const struct pump_slot *other = &b->pump[b->pump_head ^ 1];
+    const uint32_t old_take = (other->n_blocks > 0 && other->ring_held) ? (uint32_t)other->n_blocks * bl : 0;
     for (int s = 0; s < taken; s++) {
       fmd_ingest *g = b->ingest[s];
       pthread_mutex_lock(&g->m);
-      uint32_t r = take;
-      const uint32_t d = g->debt < r ? g->debt : r;
-      g->debt -= d;
-      r -= d;
+      const uint32_t mine = g->debt > old_take ? g->debt - old_take : 0;      /* eaten from this job's bytes */
+      const uint32_t eaten = mine < take ? mine : take;
+      g->debt -= eaten;
+      const uint32_t r = take - eaten;
       g->inflight -= r < g->inflight ? r : g->inflight;
       pthread_mutex_unlock(&g->m);
     }

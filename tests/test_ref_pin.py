@@ -51,6 +51,9 @@ def test_reference_library_is_the_pinned_one(tmp_path, monkeypatch):
     assert st is not None and st["pinned"], st
     assert st["slices_sha256"] == B.load_pin()["slices_sha256"]
     assert st["so_sha256"] == st["so_sha256_on_disk"]
+    # ... and so is the ring library (rtlsdr_callback :790-837 with the two reference headers it includes)
+    assert st["ring_pinned"] and st["ring_sha256"] == B.load_pin()["ring_sha256"], st
+    assert st["ring_so_sha256"] == st["ring_so_sha256_on_disk"]
     # a library that is not the recorded one, or lines that are not the pinned ones, are not "the reference"
     fake = tmp_path / "_ref"
     shutil.copytree(B.OUT, fake)
