@@ -125,9 +125,13 @@ struct demod_state {      /* include/rtl_fm_player.h:127-175 */
  * one struct.  They return void like the originals; an unusable device or an
  * unsupported configuration aborts with a message on stderr.
  *
+ * One synchronisation per block (round 4): the carried state stays on the device between calls; the library keeps a
+ * copy of what it last mirrored into the struct and uploads the struct's state only when the caller has changed it
+ * (reset, restore, a CPU block in between) - IQ up, kernel, {PCM, length, new state} down into one pinned block, one
+ * wait.  bench.py's `single_stream` leg: 0.10 ms per 262144-byte block against 1.04 ms for the reference on one host core.
+ *
  * Limits of this surface (it serves one dongle, like the program it drops into; many streams
  * belong on the batch API below):
- *   - every block pays three synchronous round trips (state up, IQ up + PCM down, state down);
  *   - the device side of a struct is found through a registry keyed by the struct's address
  *     (the reference struct has no spare field): at most 64 demod_state objects at a time, a
  *     65th aborts; fmd_demod_release (or deinit_lp_real_f32) frees a slot;
@@ -161,17 +165,19 @@ void fmd_demod_release(struct demod_state *d);
 
 /* arithmetic contract */
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
-#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build (FMD_MATH_FAST_MFMA unless the
-                             environment says FMD_MFMA=0).  The fast families want the device's CUs to themselves: a
-                             kernel whose waves share their SIMDs and issue MFMAs with 128-bit operands (the bf16 / f16 / int8
-                             opcodes new in gfx950) was seen to corrupt their results - hipBLASLt's GEMMs beside them were not;
-                             FMD_MATH_EXACT was not affected */
+#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_C
+                             for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
+                             the environment can pin a family: FMD_MFMA=0 vector ALU only, 1 stage A only, 2 (default) stages A
+                             and C.  fmd_batch_math() says what a batch runs.  (Round 3's warning about sharing the device with
+                             other MFMA kernels is obsolete: the one instruction form that went wrong beside them is gone from
+                             the kernels and kept out by tools/isa_lint.py - profiles/r04_pk_opsel_hazard.md.) */
 #define FMD_MATH_FAST_VALU 2   /* +-1 LSB, vector ALU only: fused multiply-adds in the reference's summation order */
 #define FMD_MATH_FAST_MFMA 3   /* +-1 LSB, matrix pipe beside the vector ALU: the /8 decimator as exact int8 products
                                   of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8) */
-#define FMD_MATH_FAST_MFMA_C 4 /* ... and, for 90-tap stereo, the three MPX filters as banded-Toeplitz products on
-                                  v_mfma_f32_16x16x4_f32 (exact fp32 multiply-adds).  Measured SLOWER than _MFMA on
-                                  MI355X: kept selectable and tested, never the default */
+#define FMD_MATH_FAST_MFMA_C 4 /* ... and, for 90-tap stereo, the three MPX filters as banded-Toeplitz products of int8 limbs
+                                  (samples round(v 2^20), taps round(h 2^qf), exact integer sums) on the same opcode: the
+                                  default of FMD_MATH_FAST where it applies; other configurations run
+                                  FMD_MATH_FAST_MFMA under this name */
 
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
