@@ -218,7 +218,9 @@ typedef struct fmd_stream_state {
 /* Optional stage taps for debugging / parity tests: device pointers or NULL.
  * Shapes per stream and block, M = block_len / 16:
  *   y [2*M] f32, v [M] f32 (before the Q1 overwrite), mpx [M] f32 (resampler
- *   output before de-emphasis, result_len entries used).  prof: see below. */
+ *   output before de-emphasis, result_len entries used).  prof: see below.
+ * A launch with at least one tap runs the debug build of its kernel (same arithmetic, plus the checks
+ * and stores the taps need); launches without taps run the build that has none of them (~1 % faster). */
 typedef struct fmd_debug_taps {
   void *y, *v, *mpx;
   void *prof;   /* i64 [n_streams][16]: shader-clock cycles per stage, summed over the launch
