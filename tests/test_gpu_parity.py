@@ -117,6 +117,37 @@ def test_stage_taps_bit_identical(R, lcg40):
         assert np.array_equal(pcm[k * b.pcm_stride:k * b.pcm_stride + n].cpu().numpy(), p)
 
 
+@pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_debug_build_and_plain_build_give_the_same_pcm(R, lcg40, name, math):
+    """Every fused kernel exists twice: the build that serves fmd_debug_taps and the one without their checks
+    (launches without taps).  Same arithmetic: PCM, lengths and the carried state must be bit-identical - noise
+    input, so the cold paths run in both."""
+    import torch
+    nb = 4
+    m = R.MATH_EXACT if math == "exact" else R.MATH_FAST
+    dev = torch.device("cuda:0")
+    iq = torch.from_numpy(lcg40[: nb * BL].copy()).to(dev)
+    out = []
+    for taps in (False, True):
+        b = R.BatchDemod(R.wbfm_config(math=m, **CONFIGS[name]), 1)
+        M = BL // 16
+        pcm = torch.zeros(nb * b.pcm_stride, dtype=torch.int16, device=dev)
+        lens = torch.zeros(nb, dtype=torch.int32, device=dev)
+        if taps:
+            v = torch.zeros(nb * M, dtype=torch.float32, device=dev)
+            b.run_device(iq, nb, pcm, lens, debug={"v": v})
+        else:
+            b.run_device(iq, nb, pcm, lens)
+        b.sync()
+        st = b.get_state(0)
+        out.append((pcm.cpu().numpy(), lens.cpu().numpy(), (st.acc, st.pre_r, st.pre_j, st.pp, st.deemph_l, st.deemph_r, list(st.br)[:128])))
+        b.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][2] == out[1][2]
+
+
 def test_carried_state_matches_oracle(R, lcg40):
     nb = 5
     _, _, s = oracle_run(CONFIGS["stereo_300k"], lcg40[: nb * BL])
