@@ -591,11 +591,10 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
     HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
   }
   const int nxt = b->cur ^ 1;
-  if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev0, st));
+  /* the timing events ride on the kernel's dispatch packet (fmdk_launch): no packets of their own */
   int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state[b->cur],
-                      b->d_state[nxt], dbg, st);
+                      b->d_state[nxt], dbg, st, b->no_timing ? NULL : (void *)b->ev0, b->no_timing ? NULL : (void *)b->ev1);
   if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
-  if (!b->no_timing) HIP_TRY(hipEventRecord(b->ev1, st));
   b->cur = nxt;
   b->last_stream = st;
   b->launched = 1;

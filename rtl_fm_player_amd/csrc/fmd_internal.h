@@ -71,10 +71,11 @@ typedef struct fmdk_params {
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a
- * hipError_t (> 0).  All pointers are device pointers. */
+ * hipError_t (> 0).  All pointers are device pointers.  ev_start / ev_stop: hipEvent_t or NULL - recorded with the
+ * kernel's own dispatch packet (hipExtLaunchKernelGGL), not as packets of their own around it. */
 int fmdk_launch(const fmdk_params *p, int math, int n_streams, const void *d_iq, void *d_pcm,
                 void *d_lens, const void *d_state_in, void *d_state_out, const fmd_debug_taps *dbg,
-                void *hip_stream);
+                void *hip_stream, void *ev_start, void *ev_stop);
 /* Tiles a time chunk must replay so that every FIR history is exact and the
  * de-emphasis recurrence has converged (0: the launch must not be split). */
 int fmdk_warm_tiles(const fmdk_params *p, int math);
