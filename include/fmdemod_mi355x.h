@@ -272,6 +272,11 @@ int fmd_batch_run_device(fmd_batch *b, const void *d_iq, int n_blocks, void *d_p
 int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, void *d_pcm,
                                void *d_lens, void *hip_stream, const fmd_debug_taps *dbg);
 int fmd_batch_sync(fmd_batch *b);
+/* The buffers of a launch must be READY on the stream it runs on: a caller that fills d_iq (or allocates d_pcm / d_lens from a
+ * stream-ordered allocator) on another stream synchronises that stream first - or calls this: everything queued on
+ * producer_stream so far happens before whatever this batch launches afterwards on its OWN stream (one event record + one wait,
+ * no host synchronisation).  Launches with an explicit hip_stream are ordered by that stream and need none of it. */
+int fmd_batch_wait_stream(fmd_batch *b, void *producer_stream);
 
 /* Host-buffer convenience (H2D, run, D2H, sync); same layouts in host memory. */
 int fmd_batch_run_host(fmd_batch *b, const uint8_t *iq, int n_blocks, int16_t *pcm,

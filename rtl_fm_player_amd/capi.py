@@ -98,7 +98,7 @@ _EXPORTS = [
     "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release",
     "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
     "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_batch_set_time_split", "fmd_batch_run_device", "fmd_batch_run_device_debug",
-    "fmd_batch_sync", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
+    "fmd_batch_sync", "fmd_batch_wait_stream", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
     "fmd_ingest_buffered", "fmd_ingest_dropped", "fmd_ingest_mute", "fmd_ingest_set_overflow", "fmd_ingest_pop",
@@ -149,6 +149,7 @@ def lib():
     L.fmd_batch_reset.argtypes = [vp]
     L.fmd_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.fmd_batch_set_timing.argtypes = [vp, C.c_int]
+    L.fmd_batch_wait_stream.argtypes = [vp, vp]
     L.fmd_batch_kernel_name.argtypes = [vp]
     L.fmd_batch_kernel_name.restype = C.c_char_p
     L.fmd_last_error.restype = C.c_char_p
@@ -239,7 +240,8 @@ class BatchDemod:
     __del__ = close
 
     def run_device(self, d_iq, n_blocks, d_pcm, d_lens, hip_stream=None, debug=None):
-        """Asynchronous device-resident run (tensors or raw device addresses)."""
+        """Asynchronous device-resident run (tensors or raw device addresses) on `hip_stream` (None: the batch's own stream - the
+        buffers must be ready there: torch.cuda.synchronize(), or wait_stream(), after producing them on torch's stream)."""
         if debug is None:
             rc = lib().fmd_batch_run_device(self._h, _ptr(d_iq), n_blocks, _ptr(d_pcm), _ptr(d_lens),
                                             _ptr(hip_stream))
@@ -252,6 +254,15 @@ class BatchDemod:
 
     def sync(self):
         _check(lib().fmd_batch_sync(self._h), "fmd_batch_sync")
+
+    def wait_stream(self, producer_stream=None):
+        """Order this batch's own stream behind what is queued on `producer_stream` (a hipStream_t address; None: torch's current
+        stream).  run_device() with hip_stream=None launches on the batch's OWN stream: tensors another stream is still filling -
+        or memory torch's allocator handed out in its stream's order - are only safe after this or a synchronisation."""
+        if producer_stream is None:
+            import torch
+            producer_stream = torch.cuda.current_stream().cuda_stream
+        _check(lib().fmd_batch_wait_stream(self._h, _ptr(producer_stream)), "fmd_batch_wait_stream")
 
     def run_host(self, iq, n_blocks):
         """iq: uint8 [n_streams, n_blocks, block_len] -> (pcm [S, B, stride] int16, lens [S, B])."""

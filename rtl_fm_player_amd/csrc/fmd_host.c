@@ -614,6 +614,20 @@ int fmd_batch_sync(fmd_batch *b) {
   return FMD_OK;
 }
 
+int fmd_batch_wait_stream(fmd_batch *b, void *producer_stream) {
+  if (!b) return fail(FMD_E_ARG, "NULL batch");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t ps = (hipStream_t)producer_stream;
+  if (ps == b->stream) return FMD_OK;
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ps);
+  if (e == hipSuccess) e = hipStreamWaitEvent(b->stream, ev, 0);
+  hipEventDestroy(ev);                         /* (released by the runtime once the recorded work has completed) */
+  if (e != hipSuccess) return fail(FMD_E_HIP, "fmd_batch_wait_stream: %s", hipGetErrorString(e));
+  return FMD_OK;
+}
+
 int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms) {
   if (!b || !ms) return fail(FMD_E_ARG, "NULL argument");
   if (!b->timed) return fail(FMD_E_STATE, "no kernel has been launched yet");

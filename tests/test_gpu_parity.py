@@ -148,6 +148,34 @@ def test_debug_build_and_plain_build_give_the_same_pcm(R, lcg40, name, math):
     assert out[0][2] == out[1][2]
 
 
+def test_wait_stream_orders_the_batch_behind_torch(R, lcg40):
+    """run_device(hip_stream=None) launches on the batch's own stream.  Here the IQ bytes are still on their way when it is called - an
+    asynchronous copy queued on torch's stream behind a second of matrix products - and fmd_batch_wait_stream is all that orders the
+    two: without it the kernel would read the zeros the buffer held before."""
+    import torch
+    nb = 3
+    dev = torch.device("cuda:0")
+    want, wl, _ = oracle_run(CONFIGS["stereo_300k"], lcg40[: nb * BL])
+    b = R.BatchDemod(R.wbfm_config(math=R.MATH_EXACT, **CONFIGS["stereo_300k"]), 1)
+    host = torch.from_numpy(lcg40[: nb * BL].copy()).pin_memory()
+    iq = torch.zeros(nb * BL, dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(nb * b.pcm_stride, dtype=torch.int16, device=dev)
+    lens = torch.zeros(nb, dtype=torch.int32, device=dev)
+    big = torch.randn((8192, 8192), device=dev)
+    torch.cuda.synchronize()
+    for _ in range(30):
+        big = (big @ big) * 1e-4                     # ~a second of queued work in front of the copy
+    iq.copy_(host, non_blocking=True)
+    b.wait_stream()                                   # torch's current stream
+    b.run_device(iq, nb, pcm, lens)
+    b.sync()
+    got_l = lens.cpu().numpy()
+    assert np.array_equal(got_l, wl)
+    got = np.concatenate([pcm[k * b.pcm_stride:k * b.pcm_stride + int(got_l[k])].cpu().numpy() for k in range(nb)])
+    assert np.array_equal(got, want)
+    b.close()
+
+
 def test_carried_state_matches_oracle(R, lcg40):
     nb = 5
     _, _, s = oracle_run(CONFIGS["stereo_300k"], lcg40[: nb * BL])
