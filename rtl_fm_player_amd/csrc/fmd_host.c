@@ -267,6 +267,16 @@ static int build_ci_scales(const fmd_taps *t, int size, fmdk_params *k) {
     int qf = 40;
     while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
     if (qf < 8) return -1;                                  /* taps of magnitude 2^15: not a filter this form was made for */
+    /* The kernel reads its int32 limb-pair sums as floats (accumulators started at the bits of 1.5 x 2^23, mpx_tile_i8): every weight
+     * class must stay inside +-2^22 for ANY samples (limbs within +-128).  Classes by tap limb: class 0 = T0, class 1 = T0 + T1,
+     * class 2 = T0 + T1 + T2, class 3 = T1 + T2 (the sample limb is what is left of the class index). */
+    double sum_abs[3] = {0.0, 0.0, 0.0};
+    for (int u = 0; u < 90; u++) {
+      const long long E = llround((double)taps[f][u < 45 ? u : 89 - u] * ldexp(1.0, qf));
+      const unsigned q = ((unsigned)(int)E + 0x808080u) ^ 0x808080u;
+      for (int l = 0; l < 3; l++) sum_abs[l] += fabs((double)(signed char)(q >> (8 * (2 - l))));
+    }
+    if (128.0 * (sum_abs[0] + sum_abs[1] + sum_abs[2]) >= 4194304.0 - 65536.0) return -1;
     k->ci_qf[f] = qf;
     k->ci_scale[f] = (float)ldexp(1.0, 32 - 20 - qf);
   }
