@@ -330,6 +330,8 @@ static void fill_params(fmd_batch *b) {
     k->flush_g = (fmax + 3) / 4 <= 64 / ch ? 4 : 8;     /* lanes: 32 groups per channel (stereo), 64 (mono) */
     if (ch == 1 && (fmax + 1) / 2 <= 64 && !tuning_env("FMD_NO_FLUSH2"))   /* (tuning builds: keep groups of four) */
       k->flush_g = 2;                                     /* mono with few frames per tile: shorter groups, fewer instructions */
+    if (ch == 2 && (fmax + 2) / 3 <= 32 && !tuning_env("FMD_NO_FLUSH3"))
+      k->flush_g = 3;                                     /* stereo likewise: groups of three fit its 32 lanes per channel up to 96 frames */
     const int on = c->deemph != 0;
     k->lam_eff = on ? c->deemph_lambda : 0.f;
     if (!on) memset(k->lam_pow, 0, sizeof(k->lam_pow));
