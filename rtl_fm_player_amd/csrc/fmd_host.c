@@ -381,6 +381,8 @@ static void fill_params(fmd_batch *b) {
   k->mode = c->mode;
   k->slow = c->rate_out2 > 0 ? c->rate_out2 : 1;
   k->fast = c->rate_out2 > 0 ? c->rate_out : 1;
+  k->inv_slow = 1.0f / (float)k->slow;      /* the estimates of the kernels' generic (no magic number) index forms */
+  k->inv_fast = 1.0f / (float)k->fast;
   k->resample = c->rate_out2 > 0;
   /* floor(n / slow) for n < 2^29 as mulhi(n, m) >> sh: with l = ceil(log2 slow), p = 29 + l and
    * m = ceil(2^p / slow) the error term m slow - 2^p is below slow, so n (m slow - 2^p) < 2^p for every

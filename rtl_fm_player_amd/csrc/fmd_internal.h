@@ -35,6 +35,8 @@ typedef struct fmdk_params {
   float log2_a;             /* log2(lambda^flush_g), -1e30 with de-emphasis off: a^(i+1) = exp2((i+1) log2_a) */
   float car_inv_k2;         /* fast stereo: 1 / K^2, K = radius of (x, y) per unit |vs| below which the
                                regenerated 38 kHz carrier is redone exactly (fmd_kernels.inc, carrier_fast) */
+  float inv_slow;           /* 1.0f / (float)slow: the generic emit-index form's estimate (made by the host: as a division in the kernel's prologue it held a register for the kernel's whole life) */
+  float inv_fast;           /* 1.0f / (float)fast: tile_frames' estimate, likewise */
   float car_inv_k2_l2;      /* ... and 1 / (L K)^2: below L K the redo recomputes the window from the IQ words, between L K and K it
                                sums the worker's own window in the reference's order (redo_carrier, step 0)                 */
   int32_t size, half, mode;
