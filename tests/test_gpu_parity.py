@@ -176,6 +176,37 @@ def test_wait_stream_orders_the_batch_behind_torch(R, lcg40):
     b.close()
 
 
+def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R, lcg40):
+    """The default stereo family reads its int32 limb-pair sums as floats (accumulators started at the bits of 1.5 x 2^23), which needs every
+    weight class inside +-2^22 for ANY samples: fmd_batch_create checks the taps' limbs (build_ci_scales).  The reference's design passes;
+    a caller's filter whose every tap has three large limbs (90 x 0x7F7F7F / 2^23) does not - MATH_FAST must then resolve to the
+    family with stage A only, and still agree with the exact kernels on the same taps (a gain-of-90 filter clips: +-1 LSB where it does not)."""
+    import torch
+    cfg_kw = CONFIGS["stereo_300k"]
+    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **cfg_kw), 1)
+    assert b.math == R.MATH_FAST_MFMA_C
+    b.close()
+    taps = R.design_taps(R.wbfm_config(math=R.MATH_FAST, **cfg_kw))
+    for k in range(45):
+        taps.fs[k] = 8355711.0 / 2 ** 23            # 0x7F7F7F / 2^23: limbs (127, 127, 127)
+    out = {}
+    dev = torch.device("cuda:0")
+    nb = 2
+    iq = torch.from_numpy(lcg40[: nb * BL].copy()).to(dev)
+    for name, m in (("fast", R.MATH_FAST), ("exact", R.MATH_EXACT)):
+        b = R.BatchDemod(R.wbfm_config(math=m, volume=0.001, **cfg_kw), 1, taps=taps)
+        if name == "fast":
+            assert b.math == R.MATH_FAST_MFMA, "the L-R filter's limbs do not fit: stage C must not run on the matrix pipe"
+        pcm = torch.zeros(nb * b.pcm_stride, dtype=torch.int16, device=dev)
+        lens = torch.zeros(nb, dtype=torch.int32, device=dev)
+        b.run_device(iq, nb, pcm, lens)
+        b.sync()
+        out[name] = (pcm.cpu().numpy().astype(np.int32), lens.cpu().numpy())
+        b.close()
+    assert np.array_equal(out["fast"][1], out["exact"][1])
+    assert int(np.abs(out["fast"][0] - out["exact"][0]).max()) <= 1
+
+
 def test_carried_state_matches_oracle(R, lcg40):
     nb = 5
     _, _, s = oracle_run(CONFIGS["stereo_300k"], lcg40[: nb * BL])
