@@ -5,7 +5,7 @@
  * device buffers and carried state, the batch API, the reference-shaped
  * entry points (same names / struct layout as rtl_fm_player.c) and the
  * rtlsdr_read_async-compatible ingest ring.  All arithmetic of the hot path
- * runs in the kernels of fmd_kernels.hip; nothing here computes a sample.
+ * runs in the kernels of fmd_kernels.inc (built as fmd_kernels_{exact,fast,mfma}.hip); nothing here computes a sample.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -78,8 +78,9 @@ int fmd_device_count(void) {
 }
 
 /* Environment knobs that change the arithmetic thresholds or the kernels' shape exist only in tuning builds
- * (make EXTRA_CFLAGS=-DFMD_TUNING): the shipped library reads FMD_MFMA (kernel family behind FMD_MATH_FAST) and
- * FMD_MATH_FAST (drop-in surface) and nothing else. */
+ * (make EXTRA_CFLAGS=-DFMD_TUNING; there FMD_MFMA also pins the family behind FMD_MATH_FAST): the shipped library reads ONE
+ * variable, FMD_MATH_FAST, and only for the reference-shaped surface whose signatures have no room for the choice.  The batch
+ * API's kernel family is fmd_config.math and nothing else. */
 #ifndef FMD_CARRIER_L2_DEFAULT
 #define FMD_CARRIER_L2_DEFAULT 0.5f     /* measured: 0.125 fails 4 of the noise / hand-over tests, 0.25 and up none (r04x); 1: always the full redo */
 #endif
@@ -451,9 +452,10 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
   if (!b) return fail(FMD_E_NOMEM, "out of host memory");
   b->cfg = *cfg;
-  /* FMD_MATH_FAST = the faster of the two +-1 LSB kernel families: the matrix-pipe one, unless FMD_MFMA=0 */
+  /* FMD_MATH_FAST = the fastest +-1 LSB kernel family for the configuration (a caller who wants a particular one names it in
+   * fmd_config.math; FMD_MFMA is read by tuning builds only) */
   if (b->cfg.math == FMD_MATH_FAST) {
-    const char *e_m = getenv("FMD_MFMA");
+    const char *e_m = tuning_env("FMD_MFMA");
     const int sel = e_m ? atoi(e_m) : 2;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2 (default): stages A and C
                                                      (90-tap stereo with whole tiles; everything else runs 1, see below) */
     b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : FMD_MATH_FAST_MFMA;
@@ -886,6 +888,9 @@ void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 
     t.cwf = d->lpr.cwf;
     if (fmd_batch_create(&di->batch, &c, &t, 1, -1)) die("full_demod: fmd_batch_create");
     di->cfg = c;
+    /* a new batch starts from zeroed device state: what the struct holds (the stream so far - the reference keeps running across a
+     * change of volume, buf_len, rates or de-emphasis, all of which are in fmd_config) must be uploaded whatever the shadow says */
+    di->shadow_valid = 0;
   }
   fmd_batch *b = di->batch;
   const int size = d->lpr.size;

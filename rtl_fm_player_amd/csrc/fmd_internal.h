@@ -1,6 +1,7 @@
 /*
  * fmd_internal.h - private interface between the C host layer (fmd_host.c)
- * and the HIP kernel launcher (fmd_kernels.hip).  Not installed.
+ * and the HIP kernel launchers (fmd_kernels.inc, one translation unit per kernel family).  Not installed, not exported
+ * (csrc/fmdemod_mi355x.map).
  */
 #ifndef FMD_INTERNAL_H
 #define FMD_INTERNAL_H

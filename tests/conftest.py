@@ -22,7 +22,8 @@ def lcg40():
 
 @pytest.fixture(params=["valu", "mfma", "mfma_c"])
 def fast_math(request):
-    """The three +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST
-    resolves to), and stages A + C on the matrix pipe (selectable, measured slower)."""
+    """The +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST resolves to for
+    mono / NFM / generic filter sizes), and stages A + C on the matrix pipe (what it resolves to for 90-tap stereo with whole tiles;
+    other configurations run the stage-A family under that name)."""
     import rtl_fm_player_amd as R
     return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C}[request.param]

@@ -395,6 +395,47 @@ def test_drop_in_notices_a_caller_who_edits_the_struct(R, lcg40):
     L.deinit_lp_real_f32(C.byref(d))
 
 
+def test_drop_in_keeps_the_stream_across_a_config_change(R, lcg40):
+    """The reference keeps demodulating the same stream when its caller changes `volume` or `buf_len` between blocks (both are
+    plain fields of struct demod_state, read per call: src/rtl_fm_player.c:758-788, :711-735).  Here both live in fmd_config, so a
+    change rebuilds the single-stream batch - whose device state starts from zero: the struct's state must then be uploaded even
+    though the struct still holds exactly what the previous call mirrored into it (the upload-skip shadow)."""
+    from oracle import OracleStream
+    from rtl_fm_player_amd.capi import DemodState
+    L = R.lib()
+    d = DemodState()
+    L.demod_init(C.byref(d))
+    d.rate_in = d.rate_out = 300000
+    d.rate_out2 = 48000
+    d.deemph_lambda = L.fmd_deemph_lambda(48000, 50e-6)
+    L.init_u8_f32_table(); L.init_lp_f32(); L.init_lp_real_f32(C.byref(d))
+
+    def run(iq):
+        C.memmove(d.buf, iq.ctypes.data, iq.size)
+        d.buf_len = iq.size
+        L.rotate_90_u8_f32(C.byref(d))
+        L.full_demod(C.byref(d))
+        return np.frombuffer(d.result, dtype=np.int16, count=d.result_len).copy()
+
+    s = OracleStream(**CONFIGS["stereo_300k"])
+    pos = 0
+    for k in range(2):
+        assert np.array_equal(run(lcg40[pos:pos + BL]), s.block(lcg40[pos:pos + BL]))
+        pos += BL
+    # volume changes: the oracle continues the SAME stream (state carried over) with the new volume
+    d.volume = 1.0
+    s2 = OracleStream(**dict(CONFIGS["stereo_300k"], volume=1.0))
+    s2.set_state(s.get_state())
+    assert np.array_equal(run(lcg40[pos:pos + BL]), s2.block(lcg40[pos:pos + BL])), "the stream was reset by the volume change"
+    pos += BL
+    # buf_len changes (half a block, then a quarter, then back): same stream
+    for n in (BL // 2, BL // 4, BL):
+        assert np.array_equal(run(lcg40[pos:pos + n]), s2.block(lcg40[pos:pos + n])), "the stream was reset by buf_len %d" % n
+        pos += n
+    assert np.array_equal(run(lcg40[pos:pos + BL]), s2.block(lcg40[pos:pos + BL]))      # and on without an upload
+    L.deinit_lp_real_f32(C.byref(d))
+
+
 def test_ingest_callback_and_pump(R):
     """rtlsdr_read_async-shaped ingest: odd-sized callback buffers -> pinned ring -> batch."""
     from oracle import OracleStream, lcg_bytes

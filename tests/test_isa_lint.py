@@ -54,3 +54,19 @@ def test_kernels_have_no_scratch_and_no_spills(kind):
     bad = [(n, sc, sp) for n, sc, sp in zip(names, scratch, spills) if sc or sp]
     assert not bad, "kernels with scratch / VGPR spills: %s" % bad
     assert len(sspills) == len(names)
+
+
+def test_the_built_library_is_what_gets_linted():
+    """the lint above recompiles the sources with fixed flags; what ships is the .so.  tools/isa_lint.py --so extracts the
+    gfx950 code objects of the built library and lints their disassembly (csrc/Makefile runs it on every link): no forbidden packed
+    form, no scratch, no spills - whatever flags the library was built with."""
+    so = os.path.join(ROOT, "rtl_fm_player_amd", "libfmdemod_mi355x.so")
+    if not os.path.exists(so):
+        import rtl_fm_player_amd as R
+        R.build_library()
+    n_pk, found, kernels = isa_lint.lint_so(so)
+    assert n_pk > 1500 and len(kernels) >= 20, (n_pk, len(kernels))
+    errors = [f for f in found if f[1] == "error"]
+    assert not errors, errors[:3]
+    assert not [k for k in kernels if k[1] or k[2]], [k for k in kernels if k[1] or k[2]]
+    assert any("fmd_fused_kernel" in k[0] for k in kernels)

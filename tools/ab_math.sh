@@ -1,6 +1,7 @@
 #!/bin/bash
-# Run ON THE GPU BOX: kernel ms of the two +-1 LSB kernel families (FMD_MFMA=0: vector ALU only, FMD_MFMA=1: matrix
-# pipe; FAMILIES="0 1 2" adds the stage-C MFMA kernel) of ONE build on the same device, interleaved, two rounds per mode.   tools/ab_math.sh <tag> [modes...] [-- bench flags]
+# Run ON THE GPU BOX: kernel ms of the +-1 LSB kernel families of ONE build on the same device, interleaved, two rounds per mode.
+# Families are bench.py's --math names (fmd_config.math; the library reads no environment variable for this):
+# FAMILIES="fast-valu fast-mfma fast-mfma-c fast-mfma-d".   tools/ab_math.sh <tag> [modes...] [-- bench flags]
 TAG=$1; shift
 MODES=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do MODES+=("$1"); shift; done; [ "$1" = "--" ] && shift
 [ ${#MODES[@]} -eq 0 ] && MODES=(stereo mono nfm)
@@ -8,8 +9,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 for m in "${MODES[@]}"; do
   for round in 1 2; do
-    for f in ${FAMILIES:-0 1}; do
-      FMD_MFMA=$f timeout 300 python3 bench.py --steps 100 --no-cpu --no-e2e --no-extra --mode $m "$@" > $OUT/ab_${m}_mfma${f}_r$round.json 2>> $OUT/ab.err
+    for f in ${FAMILIES:-fast-valu fast-mfma}; do
+      timeout 300 python3 bench.py --steps 100 --no-cpu --no-e2e --no-extra --mode $m --math $f "$@" > $OUT/ab_${m}_mfma${f}_r$round.json 2>> $OUT/ab.err
       python3 - $OUT/ab_${m}_mfma${f}_r$round.json $m $f $round <<'PY'
 import json,sys
 try:

@@ -8,7 +8,11 @@ selections (op_sel all 0 or all 1 over the register sources), op_sel_hi in any c
 in every run.  The kernels therefore spell half swaps with plain 32-bit instructions, and this lint keeps the compiler (which forms such
 instructions from plain 2-vector code by itself) and later edits from bringing them back.
 
-  tools/isa_lint.py [fast|mfma|exact ...]     exit status 1 when an instruction of the forbidden form is found
+  tools/isa_lint.py [fast|mfma|exact ...]     recompile the translation units with the shipped flags and lint the assembly
+  tools/isa_lint.py --so <lib.so>             lint what a BUILT library really holds: the gfx950 code objects inside it are
+                                              extracted and disassembled (llvm-objdump), so builds with EXTRA_HIPFLAGS, -DFMD_TUNING,
+                                              other worker counts ... are checked too - csrc/Makefile runs this on every link
+  exit status 1 when an instruction of the forbidden form is found (with --so also: any kernel with scratch)
 """
 import os, re, subprocess, sys
 
@@ -23,6 +27,47 @@ def device_asm(kind, extra=()):
                     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-fno-slp-vectorize", "-S", "--cuda-device-only",
                     "-o", out, os.path.join(CSRC, "fmd_kernels_%s.hip" % kind)] + list(extra), check=True, stderr=subprocess.DEVNULL)
     return out
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def so_disassembly(so_path):
+    """Disassembly of every gfx950 code object bundled in a built shared library, and (kernel name, private segment bytes) of its
+    kernels from the code objects' notes.  Works on a copy: llvm-objdump writes the extracted bundles next to its input."""
+    import glob, shutil, tempfile
+    tmp = tempfile.mkdtemp(prefix="fmd_lint_so_")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(so_path, local)
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(glob.glob(local + ".*gfx950*"))
+        if not objs:
+            raise RuntimeError("no gfx950 code object in %s" % so_path)
+        text, kernels = [], []
+        for o in objs:
+            text.append(subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout)
+            notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", o], check=True, capture_output=True, text=True).stdout
+            names = re.findall(r"\.name:\s+(\S+)", notes)
+            scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+            spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
+            kernels += list(zip(names, scratch, spills))
+        return "\n".join(text), kernels
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def lint_so(so_path):
+    text, kernels = so_disassembly(so_path)
+    n_pk, found = 0, []
+    for no, line in enumerate(text.splitlines(), 1):
+        line = line.split("//")[0]
+        if PK.match(line):
+            n_pk += 1
+            r = check_line(line)
+            if r:
+                found.append((no, r[0], line.strip(), r[1]))
+    return n_pk, found, kernels
 
 
 def split_operands(s):
@@ -69,9 +114,21 @@ def lint_file(path):
 
 def main(kinds):
     rc = 0
+    if kinds and kinds[0] == "--so":
+        kinds = ["so:" + k for k in kinds[1:]]
     for kind in kinds:
-        path = kind if kind.endswith(".s") else device_asm(kind)
-        n_pk, found = lint_file(path)
+        if kind.startswith("so:"):
+            n_pk, found, kernels = lint_so(kind[3:])
+            bad = [k for k in kernels if k[1] or k[2]]
+            if n_pk < 500 or not kernels:
+                print("%s: %d packed-fp32 instructions in %d kernels: not the library this lint is for" % (kind, n_pk, len(kernels)))
+                rc |= 1
+            for name, sc, sp in bad:
+                print("   error: kernel %s has %d bytes of scratch, %d spilled VGPRs" % (name, sc, sp))
+            rc |= bool(bad)
+        else:
+            path = kind if kind.endswith(".s") else device_asm(kind)
+            n_pk, found = lint_file(path)
         n_err = sum(1 for f in found if f[1] == "error")
         print("%s: %d packed-fp32 instructions, %d of the forbidden form, %d other mixed selections" % (kind, n_pk, n_err, len(found) - n_err))
         seen = {}
