@@ -48,7 +48,7 @@ def parse():
                          "(tools/ramp_check.py: 0.76 ms per launch at first, 0.63 ms from then on)")
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
-    ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-c"], default="fast",
+    ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-c", "fast-mfma-d"], default="fast",
                     help="fast = the +-1 LSB kernels the library picks (matrix-pipe stage A unless FMD_MFMA=0); "
                          "fast-valu / fast-mfma / fast-mfma-c name a kernel family (A/B runs)")
     ap.add_argument("--mode", choices=["stereo", "mono", "nfm"], default="stereo",
@@ -506,7 +506,7 @@ def main():
     else:
         cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
     math_code = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
-            "fast-mfma-c": R.MATH_FAST_MFMA_C}[args.math]
+            "fast-mfma-c": R.MATH_FAST_MFMA_C, "fast-mfma-d": R.MATH_FAST_MFMA_D}[args.math]
     cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math_code, **cfg_kw)
     S, B = args.streams, args.blocks
     batch = R.BatchDemod(cfg, S, device=local)
@@ -658,9 +658,10 @@ def main():
                 "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
                 # what ran: the kernel family FMD_MATH_FAST resolved to, and which stages used the matrix pipe
                 "kernel_family": {R.MATH_EXACT: "exact", R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma",
-                                  R.MATH_FAST_MFMA_C: "fast-mfma-c"}.get(batch.math, str(batch.math)),
-                "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C),
-                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (i8 MPX filters)"}.get(batch.math, "none"),
+                                  R.MATH_FAST_MFMA_C: "fast-mfma-c", R.MATH_FAST_MFMA_D: "fast-mfma-d"}.get(batch.math, str(batch.math)),
+                "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C, R.MATH_FAST_MFMA_D),
+                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (i8 MPX filters)",
+                                R.MATH_FAST_MFMA_D: "A (i8 decimator) + C (i8 MPX filters) + D (i8 second-stage low-pass at every sample)"}.get(batch.math, "none"),
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
                 "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },

@@ -165,8 +165,8 @@ void fmd_demod_release(struct demod_state *d);
 
 /* arithmetic contract */
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
-#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_C
-                             for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
+#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_D
+                             (or _C) for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
                              a caller who wants a particular family names it here instead (the library reads no environment
                              variable for this).  fmd_batch_math() says what a batch runs.  Sharing the device with other
                              MFMA kernels: one packed-fp32 instruction form computed wrong results beside them (round 3); it is
@@ -179,8 +179,12 @@ void fmd_demod_release(struct demod_state *d);
                                   of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8) */
 #define FMD_MATH_FAST_MFMA_C 4 /* ... and, for 90-tap stereo, the three MPX filters as banded-Toeplitz products of int8 limbs
                                   (samples round(v 2^20), taps round(h 2^qf), exact integer sums) on the same opcode: the
-                                  default of FMD_MATH_FAST where it applies; other configurations run
+                                  round 4's default of FMD_MATH_FAST; other configurations run
                                   FMD_MATH_FAST_MFMA under this name */
+#define FMD_MATH_FAST_MFMA_D 5 /* ... and the second-stage low-pass of the stereo resampler: evaluated at every sample on the
+                                  matrix pipe from int8 limbs of {L+R, (L-R) x carrier}, the emit instants selected afterwards
+                                  (needs rate_out >= 4 rate_out2): the default of FMD_MATH_FAST where it applies; other
+                                  configurations run FMD_MATH_FAST_MFMA_C / _MFMA under this name */
 
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
@@ -194,7 +198,7 @@ typedef struct fmd_config {
   float volume;           /* demod_state.volume                                */
   int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
                           /* multiple of 16, >= 64                             */
-  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C) */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D) */
 } fmd_config;
 
 /* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /
@@ -244,8 +248,8 @@ void fmd_batch_destroy(fmd_batch *b);
 /* int16 slots per (stream, block) in the PCM buffer (multiple of 8). */
 int fmd_batch_pcm_stride(const fmd_batch *b);
 int fmd_batch_n_streams(const fmd_batch *b);
-/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA or FMD_MATH_FAST_MFMA_C (FMD_MATH_FAST in
- * the configuration resolves to one of the last three at creation; a named family the configuration cannot run resolves likewise). */
+/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA, FMD_MATH_FAST_MFMA_C or _MFMA_D (FMD_MATH_FAST
+ * in the configuration resolves to one of the last four at creation; a named family the configuration cannot run resolves likewise). */
 int fmd_batch_math(const fmd_batch *b);
 /* How a launch is cut into time chunks (one worker wavefront each; results do not depend on it - the tests hold the
  * library to that through this call): workers_per_cu > 0 = cut until the grid offers that many workers per CU,

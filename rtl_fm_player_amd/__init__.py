@@ -12,6 +12,7 @@ from .capi import (  # noqa: F401
     FAST_MATHS,
     MATH_FAST_MFMA,
     MATH_FAST_MFMA_C,
+    MATH_FAST_MFMA_D,
     MATH_FAST_VALU,
     BatchDemod,
     DemodState,

@@ -10,11 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("FMD_LIB_PATH") or os.path.join(_HERE, "libfmdemod_mi355x.so")   # override: kernel experiments
 
 MATH_EXACT = 0
-MATH_FAST = 1          # the faster +-1 LSB family of this build (MFMA unless FMD_MFMA=0)
+MATH_FAST = 1          # the fastest +-1 LSB family of this build for the configuration
 MATH_FAST_VALU = 2     # +-1 LSB, vector ALU only
 MATH_FAST_MFMA = 3     # +-1 LSB, /8 decimator on the matrix pipe
-MATH_FAST_MFMA_C = 4   # ... and the 90-tap stereo MPX filters (fp32 MFMA): measured slower, kept selectable
-FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C)
+MATH_FAST_MFMA_C = 4   # ... and the three 90-tap stereo MPX filters there too (int8 limbs)
+MATH_FAST_MFMA_D = 5   # ... and the stereo resampler's second-stage low-pass (at every sample, emit instants selected)
+FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C, MATH_FAST_MFMA_D)
 MAXIMUM_BUF_LENGTH = 16 * 16384
 
 

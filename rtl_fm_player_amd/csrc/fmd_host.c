@@ -133,7 +133,7 @@ static int check_config(const fmd_config *c) {
   if (c->mode < 0 || c->mode > 2) return fail(FMD_E_ARG, "lpr.mode must be 0, 1 or 2");
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
-  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_C)
+  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_D)
     return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_C");
   /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
    * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
@@ -280,8 +280,22 @@ static int build_ci_scales(const fmd_taps *t, int size, fmdk_params *k) {
     if (128.0 * (sum_abs[0] + sum_abs[1] + sum_abs[2]) >= 4194304.0 - 65536.0) return -1;
     k->ci_qf[f] = qf;
     k->ci_scale[f] = (float)ldexp(1.0, 32 - 20 - qf);
+    k->ci_scale_q[f] = (float)ldexp(1.0, 32 - qf);
   }
   return 0;
+}
+
+/* Stage D on the matrix pipe as well (resample_tile_i8): the second-stage low-pass at every sample, the emit instants selected.
+ * Needs what stage C needs (build_ci_scales) and: at most one emit among four consecutive samples (fast >= 4 slow), both
+ * magic-number index forms, and {L+R, (L-R) x carrier} inside the limbs' range |x| < 8 for any discriminator output (|v| <= pi, and
+ * what quirk Q1 can put in place of a sample: |om - os| <= 2 pi sum|fm| sum|f|) - true of any filter of the reference's design,
+ * checked for a caller's. */
+static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
+  if (!(k->resample && k->mode == 2 && k->size == 90)) return 0;
+  if ((long long)k->fast < 4LL * k->slow || !k->emit_magic || !k->tf_magic) return 0;
+  double sm = 0.0, ss = 0.0;
+  for (int u = 0; u < 45; u++) { sm += 2.0 * fabs((double)t->fm[u]); ss += 2.0 * fabs((double)t->fs[u]); }
+  return 3.1415927 * sm < 7.9 && 3.1415927 * ss < 7.9;
 }
 
 static void fill_params(fmd_batch *b) {
@@ -367,6 +381,7 @@ static void fill_params(fmd_batch *b) {
     const char *es = tuning_env("FMD_CARRIER_SCALE");   /* ... or scale the derived K */
     if (es) K *= (float)atof(es);
     k->car_inv_k2 = K > 0.f ? 1.0f / (K * K) : 3.0e38f;
+    k->car_inv_k2_q = k->car_inv_k2 < 3.0e38f * 0x1p-40f ? k->car_inv_k2 * 0x1p40f : 3.0e38f;
     /* Two levels (round 4).  A flagged sample first gets its pilot / L-R sums again from the worker's own window, in the
      * reference's ORDER of operations: that removes the order-of-summation part of the difference to the reference (what is left:
      * the window's samples are a few ulps off each, and roundings that fall differently because of it).  Only samples within
@@ -456,9 +471,10 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
    * fmd_config.math; FMD_MFMA is read by tuning builds only) */
   if (b->cfg.math == FMD_MATH_FAST) {
     const char *e_m = tuning_env("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 2;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2 (default): stages A and C
-                                                     (90-tap stereo with whole tiles; everything else runs 1, see below) */
-    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : FMD_MATH_FAST_MFMA;
+    const int sel = e_m ? atoi(e_m) : 3;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3 (default):
+                                                     stages A, C and D (90-tap stereo with whole tiles; what a configuration cannot
+                                                     run resolves downwards, see below) */
+    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : FMD_MATH_FAST_MFMA_D;
   }
   b->n_streams = n_streams;
   b->device = device;
@@ -466,6 +482,12 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   else if ((rc = fmd_design_taps(cfg, &b->taps))) { free(b); return rc; }
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
+  if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
+    /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone */
+    if (!(b->cfg.mode == 2 && b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0 &&
+          build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp)))
+      b->cfg.math = FMD_MATH_FAST_MFMA_C;
+  }
   if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {
     /* stage C on the matrix pipe: 90-tap stereo with whole tiles (block_len a multiple of 8192 bytes); anything else runs the
      * stage-A-only family, also when the caller named this one (it is a speed choice inside one +-1 LSB contract) */
@@ -473,7 +495,7 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
           build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0))
       b->cfg.math = FMD_MATH_FAST_MFMA;
   }
-  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C) {
+  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
       if (cfg->math != FMD_MATH_FAST) { free(b); return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }

@@ -71,6 +71,11 @@ typedef struct fmdk_params {
    * y = ci_scale[f] (A0 + A1 2^-8 + A2 2^-16 + A3 2^-24), ci_scale = 2^(32 - 20 - qf)  (fmd_kernels.inc, mpx_tile_i8) */
   int32_t ci_qf[3];
   float ci_scale[3];
+  /* matrix-pipe form of stage D (FMD_MATH_FAST_MFMA_D): stage C hands {L+R, (L-R) x carrier} over as round(x 2^20) in three int8 limbs,
+   * so its sums are put together at 2^20 times their value: ci_scale_q = 2^20 ci_scale, and the carrier's margin r^2 / K^2 - vs^2 is
+   * taken with the scaled vs: car_inv_k2_q = 2^40 / K^2 (fmd_kernels.inc, mpx_tile_i8<MFD>, resample_tile_i8) */
+  float ci_scale_q[3];
+  float car_inv_k2_q;
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a

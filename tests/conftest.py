@@ -20,10 +20,11 @@ def lcg40():
     return buf
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma_c"])
+@pytest.fixture(params=["valu", "mfma", "mfma_c", "mfma_d"])
 def fast_math(request):
     """The +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST resolves to for
     mono / NFM / generic filter sizes), and stages A + C on the matrix pipe (what it resolves to for 90-tap stereo with whole tiles;
-    other configurations run the stage-A family under that name)."""
+    other configurations run the stage-A family under that name), and stages A + C + D (the default for 90-tap stereo at
+    rate_out >= 4 rate_out2)."""
     import rtl_fm_player_amd as R
-    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C}[request.param]
+    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D}[request.param]
