@@ -184,7 +184,17 @@ def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R
     import torch
     cfg_kw = CONFIGS["stereo_300k"]
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **cfg_kw), 1)
-    assert b.math == R.MATH_FAST_MFMA_C
+    assert b.math == R.MATH_FAST_MFMA_D
+    b.close()
+    # stage D on the matrix pipe selects at most one emit among four consecutive samples: rate_out >= 4 rate_out2, else stage C alone
+    for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_D), (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
+                     (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA)):
+        for m in (R.MATH_FAST, R.MATH_FAST_MFMA_D):
+            b = R.BatchDemod(R.wbfm_config(math=m, **kw), 1)
+            assert b.math == want, (kw, m, b.math)
+            b.close()
+    b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, block_len=16 * 1000, **cfg_kw), 1)      # ragged tiles: stage A only
+    assert b.math == R.MATH_FAST_MFMA
     b.close()
     taps = R.design_taps(R.wbfm_config(math=R.MATH_FAST, **cfg_kw))
     for k in range(45):

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5b
-( timeout 1500 python -m pytest tests -m gpu -x -q -k "mfma_d" 2>&1 | tail -25 ) > gpurun_out/r5b/pytest_mfma_d.txt
-tail -25 gpurun_out/r5b/pytest_mfma_d.txt
-FAMILIES="fast-mfma-c fast-mfma-d" bash tools/ab_math.sh r5b stereo 2>&1 | tee gpurun_out/r5b/ab.txt
+mkdir -p gpurun_out/r5g
+( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/r5g/pytest_gpu.txt
+tail -6 gpurun_out/r5g/pytest_gpu.txt
+for s in 1 2 3 4; do timeout 600 python tools/fuzz_parity.py 400 $s 2>&1 | grep -v amdgpu | tail -1; done | tee gpurun_out/r5g/fuzz.txt

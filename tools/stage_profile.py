@@ -27,7 +27,9 @@ def main():
     import rtl_fm_player_amd as R
     BL = 262144
     dev = torch.device("cuda:0")
-    cfg = R.wbfm_config(block_len=BL, math=R.MATH_FAST if a.math == "fast" else R.MATH_EXACT,
+    fam = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
+           "fast-mfma-c": R.MATH_FAST_MFMA_C, "fast-mfma-d": R.MATH_FAST_MFMA_D}[a.math]
+    cfg = R.wbfm_config(block_len=BL, math=fam,
                         rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)
     b = R.BatchDemod(cfg, a.streams, device=0)
     import bench
