@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 BLOCK_LEN = 262144            # MAXIMUM_BUF_LENGTH, one reference block of u8 IQ
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_FP32_PEAK_TFLOPS = 157.3 # MI355X_MICROARCH.md: peak FP32 (vector), spec
+
 
 
 def parse():
@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
     ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-c", "fast-mfma-d"], default="fast",
-                    help="fast = the +-1 LSB kernels the library picks (matrix-pipe stage A unless FMD_MFMA=0); "
-                         "fast-valu / fast-mfma / fast-mfma-c name a kernel family (A/B runs)")
+                    help="fast = the +-1 LSB kernel family the library picks for the configuration; "
+                         "fast-valu / fast-mfma / fast-mfma-c / fast-mfma-d name one (A/B runs)")
     ap.add_argument("--mode", choices=["stereo", "mono", "nfm"], default="stereo",
                     help="stereo/mono: 2.4 Msps WBFM (rate_in 300k -> 48k); nfm: 200 ksps (25k -> 12.5k mono)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D-inclusive leg (e2e_h2d)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs of the line: `sustained` (>= --sustained-seconds of back-to-back launches) "
-                         "and `noise_input` (the same workload on uniform random bytes, parity-checked)")
+                         "`noise_input` / `quiet_input` (the same workload on uniform random bytes / on bytes in {127, 128} with mute "
+                         "fills, parity-checked) and `modes` (mono and NFM on the same device)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0)
     ap.add_argument("--e2e-streams", type=int, default=64)
     ap.add_argument("--e2e-jobs", type=int, default=20)
@@ -274,6 +275,34 @@ def measured_traffic(config):
                 w.get("kernel_family", {"fast": "fast-valu"}.get(w.get("math"), w.get("math"))) == config.get("kernel_family"):
             best = (int(t["traffic_bytes_per_launch"]), os.path.basename(f))
     return best
+
+
+def measured_busy(summary_name):
+    """Busy fractions of the CU's units over the kernel's duration, from the PMC passes of the committed profile summary the traffic
+    figure comes from (tools/profile_round.sh; counters per launch): vector ALU = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), matrix
+    pipe = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x cycles), LDS = SQ_LDS_IDX_ACTIVE / (CUs x cycles) where the summary holds it
+    (SQ_ACTIVE_INST_LDS x 4 otherwise), cycles = GRBM_GUI_ACTIVE / 8 XCDs.  Measurements of the profiled build, not of this run."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", summary_name)))
+    except (OSError, ValueError):
+        return None
+    c = {}
+    for grp in d.values():
+        if isinstance(grp, dict):
+            for k, v in grp.items():
+                if isinstance(v, dict) and "mean_per_launch" in v:
+                    c[k] = float(v["mean_per_launch"])
+    if not c.get("GRBM_GUI_ACTIVE") or "SQ_ACTIVE_INST_VALU" not in c:
+        return None
+    cyc, simds, cus = c["GRBM_GUI_ACTIVE"] / 8.0, 1024.0, 256.0
+    out = {"valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cyc), 3),
+           "mfma": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (simds * cyc), 3),
+           "lds": round(c["SQ_LDS_IDX_ACTIVE"] / (cus * cyc), 3) if "SQ_LDS_IDX_ACTIVE" in c else
+                  round(c.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (cus * cyc), 3),
+           "cycles_per_xcd_under_counters": int(cyc), "source": "profiles/" + summary_name,
+           "note": "rocprofv3 PMC per launch of the profiled build: SQ_ACTIVE_INST_VALU x 4, SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x "
+                   "(GRBM_GUI_ACTIVE / 8) cycles; LDS over 256 CUs"}
+    return out
 
 
 def kfd_gpu_count():
@@ -602,8 +631,20 @@ def main():
                           int(pcm.view(torch.int16).sum().item()), force=args.force_dist)
     total_samples, elapsed = rep["samples"], rep["elapsed_s"]
 
-    # ---- extra legs (never `value`): a sustained run and the worst-case input ----
-    sustained = noise_leg = None
+    # ---- extra legs (never `value`): a sustained run, the worst-case and the quiet inputs, the other modes ----
+    sustained = noise_leg = quiet_leg = modes_leg = None
+
+    def input_leg(iq_t, what):
+        """parity gate on EVERY stream, then the same preheat the timed workload got, then --steps timed launches"""
+        par = None if args.no_check else parity_gate(iq_t)
+        timed_launches(iq_t, max(args.preheat, args.warmup, 2))
+        wall, k_ms = timed_launches(iq_t, args.steps)
+        batch.reset()
+        return {"data": what, "steps": args.steps, "untimed_launches_before_timing": max(args.preheat, args.warmup, 2),
+                "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(k_ms, 4),
+                "value": round(samples_per_step * args.steps / wall / 1e6, 1), "parity": par,
+                "slowdown_vs_timed_input": round(k_ms / kernel_ms, 3)}
+
     if not args.no_extra and not args.dry_run:
         n_sus = max(args.steps, int(math.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
         wall, k_ms = timed_launches(iq, n_sus)
@@ -618,19 +659,71 @@ def main():
             gn.manual_seed(54321 + rank)
             iq_n = torch.randint(0, 256, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gn)
             torch.cuda.synchronize(dev)
-            par_n = None if args.no_check else parity_gate(iq_n)
-            timed_launches(iq_n, max(2, args.warmup))
-            wall, k_ms = timed_launches(iq_n, args.steps)
-            noise_leg = {"data": "synthetic uniform random bytes", "steps": args.steps,
-                         "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(k_ms, 4),
-                         "value": round(samples_per_step * args.steps / wall / 1e6, 1), "parity": par_n,
-                         "slowdown_vs_timed_input": round(k_ms / kernel_ms, 3)}
+            noise_leg = input_leg(iq_n, "synthetic uniform random bytes")
+            # quiet input: bytes in {127, 128} (a dongle without an antenna) with the reference's own mute fill - 4096 bytes of 127
+            # at the head of every fourth block (src/rtl_fm_player.c:805-810) - and one stream in eight all-127: every decimated
+            # sample lies next to the origin, where the reference's own rounding decides the phase and the +-1 LSB kernels
+            # fall back to its arithmetic tile by tile
+            iq_n.copy_(torch.randint(127, 129, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gn))
+            iq_n[:, ::4, :4096] = 127
+            iq_n[::8] = 127
+            torch.cuda.synchronize(dev)
+            quiet_leg = input_leg(iq_n, "synthetic quiet input: bytes in {127, 128}, 4096-byte mute fills of 127, one stream in eight constant 127")
             del iq_n
-            batch.reset()
+        if world == 1 and args.mode == "stereo" and args.math == "fast":
+            # the other modes of the path on this device, same shape of run (BASELINE.json configs[0] / [4] at 256 streams): never `value`
+            modes_leg = {}
+            for mname, mkw, rate in (("mono", dict(rate_in=300000, rate_out2=48000, mode=1), 2.4e6),
+                                     ("nfm", dict(rate_in=25000, rate_out2=12500, mode=1), 200e3)):
+                mb = R.BatchDemod(R.wbfm_config(block_len=BLOCK_LEN, math=math_code, **mkw), S, device=local)
+                miq = synth_fm_iq(torch, dev, S, B * BLOCK_LEN // 2, rate, mname != "nfm", 12345 + rank).view(S, B, BLOCK_LEN)
+                mpcm = torch.zeros((S, B, mb.pcm_stride), dtype=torch.int16, device=dev)
+                mlens = torch.zeros((S, B), dtype=torch.int32, device=dev)
+                torch.cuda.synchronize(dev)                 # the launches go to `stream`, torch made these on its own
+                mpar = None
+                if not args.no_check:
+                    from concurrent.futures import ThreadPoolExecutor
+                    from oracle import OracleStream
+                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    h_iq, h_pcm, h_lens = miq.cpu().numpy(), mpcm.cpu().numpy(), mlens.cpu().numpy()
+
+                    def mcheck(si):
+                        want, wl = OracleStream(**mkw).run(h_iq[si].reshape(-1), BLOCK_LEN)
+                        if not np.array_equal(h_lens[si], wl):
+                            return 1 << 20
+                        got = np.concatenate([h_pcm[si, b, :wl[b]] for b in range(B)])
+                        return int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()) if got.size else 0
+
+                    with ThreadPoolExecutor(max(1, min(usable_cores(), 32))) as ex:
+                        worst = max(ex.map(mcheck, range(S)))
+                    assert worst <= 1, "%s: PCM differs from the CPU oracle by %d LSB" % (mname, worst)
+                    mpar = {"max_abs_lsb": worst, "tolerance_lsb": 1, "streams_checked": S}
+                    mb.reset()
+                mb.set_timing(False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(max(args.preheat, args.warmup, 2)):
+                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                w0 = time.perf_counter()
+                e0.record(stream)
+                for _ in range(args.steps):
+                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+                e1.record(stream)
+                torch.cuda.synchronize(dev)
+                mwall, mk = time.perf_counter() - w0, e0.elapsed_time(e1) / args.steps
+                mbytes = S * B * BLOCK_LEN + int(mlens.sum().item()) * 2
+                modes_leg[mname] = {
+                    "workload": "%d concurrent %s streams per GPU x %d blocks" % (S, "2.4 Msps mono WBFM" if mname == "mono" else "200 ksps narrow-FM mono", B),
+                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma"}.get(mb.math, str(mb.math)),
+                    "steps": args.steps, "kernel_ms": round(mk, 4), "ms_per_step": round(mwall / args.steps * 1e3, 4),
+                    "value": round(samples_per_step * args.steps / mwall / 1e6, 1), "unit": "Msamples/s",
+                    "algorithmic_bytes_per_launch": mbytes, "achieved_gbs": round(mbytes / (mk * 1e-3) / 1e9, 1),
+                    "frac": round(mbytes / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "parity": mpar}
+                del mb, miq, mpcm, mlens
 
     if rank == 0:
         copy_gbs = copy_bandwidth(torch, dev, stream) if S * B * BLOCK_LEN <= (1 << 31) else 0.0
-        flop_per_sample = 64 if stereo else 21
         value = total_samples / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -644,7 +737,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32" if batch.math in (R.MATH_EXACT, R.MATH_FAST_VALU) else
+                      "f32 (stage A: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA else
+                      "f32 (stages A, C: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA_C else
+                      "f32 (stages A, C, D: int8-limb fixed point, exact sums)"),
             "data": ("synthetic FM broadcast per stream (stereo multiplex: 19 kHz pilot + L-R DSB, tones, +-75 kHz)"
                      if args.data == "fm" and args.mode != "nfm" else
                      "synthetic narrow FM per stream (tone, +-5 kHz)" if args.data == "fm" else
@@ -672,12 +768,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                # secondary roofline: the path is fp32-VALU-issue bound, not HBM bound;
-                # algorithmic flop per complex sample (stereo 64, mono / NFM 21) against the vector fp32 peak
-                "valu_fp32": {"flop_per_sample": flop_per_sample,
-                              "achieved_tflops": round(value * 1e6 * flop_per_sample / 1e12 / world, 2),
-                              "peak_tflops": VALU_FP32_PEAK_TFLOPS,
-                              "frac": round(value * 1e6 * flop_per_sample / 1e12 / world / VALU_FP32_PEAK_TFLOPS, 4)},
+                # what the CU's units were doing (counter-derived, filled in below where a committed profile matches this workload)
+                "busy": None,
                 "copy_kernel_gbs": round(copy_gbs, 1),           # measured d2d copy on this device (read + write)
                 "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None,
                 "kernel_ms": round(kernel_ms, 4),
@@ -689,12 +781,17 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = "profiles/" + tr[1]
+            out["roofline"]["busy"] = measured_busy(tr[1])
         if parity:
             out["parity"] = parity
         if sustained:
             out["sustained"] = sustained
         if noise_leg:
             out["noise_input"] = noise_leg
+        if quiet_leg:
+            out["quiet_input"] = quiet_leg
+        if modes_leg:
+            out["modes"] = modes_leg
         out["per_rank"] = rep["per_rank"]                      # samples, kernel ns per launch, PCM checksum of each rank
         if rep.get("backend"):
             out["counters_gathered_over"] = rep["backend"]     # "nccl" (= RCCL): all_reduce(MAX) + all_gather ran

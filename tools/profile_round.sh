@@ -21,6 +21,7 @@ echo "== pmc SQ"
 timeout 200 rocprofv3 --kernel-include-regex fmd_fused --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq.log
 timeout 200 rocprofv3 --kernel-include-regex fmd_fused --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq2.log
 timeout 200 rocprofv3 --kernel-include-regex fmd_fused --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq3 -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq3.log
+timeout 200 rocprofv3 --kernel-include-regex fmd_fused --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq4 -- $PMCBENCH > /dev/null 2>$OUT/pmc_sq4.log
 python3 $ROOT/tools/summarize_profile.py $TAG $OUT $ROOT/gpurun_out/$TAG
 cp $OUT/bench_unprofiled.json $OUT/bench_traced.json $ROOT/gpurun_out/$TAG/ 2>/dev/null
 du -sh $OUT $ROOT/gpurun_out/$TAG

@@ -64,7 +64,7 @@ def pmc(dirname):
     return {k: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for k, v in acc.items()}
 
 
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"):
     c = pmc(d)
     if c:
         out[d] = c
