@@ -111,7 +111,7 @@ def test_bench_line_contract(R):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank", "parity", "e2e_h2d"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"].startswith("f32")
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
@@ -122,6 +122,12 @@ def test_bench_line_contract(R):
     assert set(cb["configs_single_thread"]) == {"mono_2.4Msps", "stereo_2.4Msps", "nfm_200ksps"}
     assert d["parity"]["max_abs_lsb"] <= 1 and d["e2e_h2d"]["value"] > 100 and d["e2e_h2d"]["pcie_gbs"] > 0.2
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["kernel_ns"] > 0
+    # the extra legs (never `value`): every stream parity-checked on the worst-case and the quiet inputs, mono and NFM on the same device
+    for leg in ("noise_input", "quiet_input"):
+        assert d[leg]["parity"]["max_abs_lsb"] <= 1 and d[leg]["parity"]["streams_checked"] == 32 and d[leg]["kernel_ms"] > 0
+    assert set(d["modes"]) == {"mono", "nfm"}
+    for m in d["modes"].values():
+        assert m["parity"]["max_abs_lsb"] <= 1 and 0 < m["frac"] < 1 and m["kernel_ms"] > 0
 
 
 def test_rccl_counter_gather_runs_on_one_gpu(R):

@@ -57,8 +57,27 @@ def so_disassembly(so_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+SCRATCH_OP = re.compile(r"^\s+(scratch_(?:load|store)\w*|buffer_(?:load|store)\w*\s.*\boffen\b.*\bs\[0:3\])")
+
+
+def kernels_touching_scratch(text):
+    """Kernel symbols whose code holds a scratch access.  (hipcc leaves a private segment of a few bytes on some kernels whose SGPR
+    spills all went to VGPR lanes - a frame object nothing reads or writes; what must not happen is an ACCESS: a reload in the tile loop
+    waits on vmcnt and drains the IQ words in flight.)"""
+    hit, cur = [], None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+        elif cur and SCRATCH_OP.match(line.split("//")[0]) and cur not in hit:
+            hit.append(cur)
+    return hit
+
+
 def lint_so(so_path):
     text, kernels = so_disassembly(so_path)
+    touching = kernels_touching_scratch(text)
+    kernels = [(n, sc, sp, n in touching) for n, sc, sp in kernels]
     n_pk, found = 0, []
     for no, line in enumerate(text.splitlines(), 1):
         line = line.split("//")[0]
@@ -119,12 +138,15 @@ def main(kinds):
     for kind in kinds:
         if kind.startswith("so:"):
             n_pk, found, kernels = lint_so(kind[3:])
-            bad = [k for k in kernels if k[1] or k[2]]
+            bad = [k for k in kernels if k[2] or k[3]]
             if n_pk < 500 or not kernels:
                 print("%s: %d packed-fp32 instructions in %d kernels: not the library this lint is for" % (kind, n_pk, len(kernels)))
                 rc |= 1
-            for name, sc, sp in bad:
-                print("   error: kernel %s has %d bytes of scratch, %d spilled VGPRs" % (name, sc, sp))
+            for name, sc, sp, touch in bad:
+                print("   error: kernel %s: %d spilled VGPRs, %s its %d bytes of scratch" % (name, sp, "accesses" if touch else "does not access", sc))
+            for name, sc, sp, touch in kernels:
+                if sc and not sp and not touch:
+                    print("   note: kernel %s has a private segment of %d bytes it never accesses (SGPR spill slots that went to VGPR lanes)" % (name, sc))
             rc |= bool(bad)
         else:
             path = kind if kind.endswith(".s") else device_asm(kind)
