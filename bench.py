@@ -715,7 +715,7 @@ def main():
                 mbytes = S * B * BLOCK_LEN + int(mlens.sum().item()) * 2
                 modes_leg[mname] = {
                     "workload": "%d concurrent %s streams per GPU x %d blocks" % (S, "2.4 Msps mono WBFM" if mname == "mono" else "200 ksps narrow-FM mono", B),
-                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma"}.get(mb.math, str(mb.math)),
+                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_D: "fast-mfma-d"}.get(mb.math, str(mb.math)),
                     "steps": args.steps, "kernel_ms": round(mk, 4), "ms_per_step": round(mwall / args.steps * 1e3, 4),
                     "value": round(samples_per_step * args.steps / mwall / 1e6, 1), "unit": "Msamples/s",
                     "algorithmic_bytes_per_launch": mbytes, "achieved_gbs": round(mbytes / (mk * 1e-3) / 1e9, 1),
@@ -740,7 +740,7 @@ def main():
             "dtype": ("f32" if batch.math in (R.MATH_EXACT, R.MATH_FAST_VALU) else
                       "f32 (stage A: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA else
                       "f32 (stages A, C: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA_C else
-                      "f32 (stages A, C, D: int8-limb fixed point, exact sums)"),
+                      "f32 (stages A, C, D: int8-limb fixed point, exact sums)" if stereo else "f32 (stages A, D: int8-limb fixed point, exact sums)"),
             "data": ("synthetic FM broadcast per stream (stereo multiplex: 19 kHz pilot + L-R DSB, tones, +-75 kHz)"
                      if args.data == "fm" and args.mode != "nfm" else
                      "synthetic narrow FM per stream (tone, +-5 kHz)" if args.data == "fm" else
@@ -757,7 +757,8 @@ def main():
                                   R.MATH_FAST_MFMA_C: "fast-mfma-c", R.MATH_FAST_MFMA_D: "fast-mfma-d"}.get(batch.math, str(batch.math)),
                 "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C, R.MATH_FAST_MFMA_D),
                 "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (i8 MPX filters)",
-                                R.MATH_FAST_MFMA_D: "A (i8 decimator) + C (i8 MPX filters) + D (i8 second-stage low-pass at every sample)"}.get(batch.math, "none"),
+                                R.MATH_FAST_MFMA_D: ("A (i8 decimator) + C (i8 MPX filters) + D (i8 second-stage low-pass at every sample)" if stereo else
+                                                     "A (i8 decimator) + D (i8 low-pass at every sample)")}.get(batch.math, "none"),
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
                 "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },

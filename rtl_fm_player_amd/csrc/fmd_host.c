@@ -290,7 +290,31 @@ static int build_ci_scales(const fmd_taps *t, int size, fmdk_params *k) {
  * magic-number index forms, and {L+R, (L-R) x carrier} inside the limbs' range |x| < 8 for any discriminator output (|v| <= pi, and
  * what quirk Q1 can put in place of a sample: |om - os| <= 2 pi sum|fm| sum|f|) - true of any filter of the reference's design,
  * checked for a caller's. */
+/* The 128-tap mono path's one filter in the same fixed-point form (resample_mono_i8): T = round(fm 2^qf) in three balanced int8 limbs,
+ * every weight class of the limb-pair sums inside +-2^22 for any samples. */
+static int build_ci_scales_mono(const fmd_taps *t, int size, fmdk_params *k) {
+  if (size != 128) return -1;
+  double mx = 0.0, sum_abs = 0.0, sa = 0.0;
+  for (int u = 0; u < 64; u++) { mx = fmax(mx, fabs((double)t->fm[u])); sa += 2.0 * fabs((double)t->fm[u]); }
+  if (!(mx > 0.0) || !isfinite(mx) || !(3.1415927 * sa < 7.9)) return -1;      /* (and the samples inside the limbs' range: |v| <= pi) */
+  int qf = 40;
+  while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
+  if (qf < 8) return -1;
+  for (int u = 0; u < 128; u++) {
+    const long long E = llround((double)t->fm[u < 64 ? u : 127 - u] * ldexp(1.0, qf));
+    const unsigned q = ((unsigned)(int)E + 0x808080u) ^ 0x808080u;
+    for (int l = 0; l < 3; l++) sum_abs += fabs((double)(signed char)(q >> (8 * (2 - l))));
+  }
+  if (128.0 * sum_abs >= 4194304.0 - 65536.0) return -1;
+  k->ci_qf[0] = qf;
+  k->ci_scale[0] = (float)ldexp(1.0, 32 - 20 - qf);
+  k->ci_scale_q[0] = (float)ldexp(1.0, 32 - qf);
+  return 0;
+}
+
 static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
+  if (k->resample && k->mode == 1 && k->size == 128)       /* mono: the same selection rule (at most one emit among four samples) */
+    return (long long)k->fast >= 4LL * k->slow && k->emit_magic && k->tf_magic;
   if (!(k->resample && k->mode == 2 && k->size == 90)) return 0;
   if ((long long)k->fast < 4LL * k->slow || !k->emit_magic || !k->tf_magic) return 0;
   double sm = 0.0, ss = 0.0;
@@ -483,9 +507,14 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
   if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
-    /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone */
-    if (!(b->cfg.mode == 2 && b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0 &&
-          build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp)))
+    /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone.
+     * 128-tap mono: stage D on the matrix pipe under the same name (there is no stage C), otherwise stage A alone. */
+    const int whole = b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0;
+    if (b->cfg.mode == 1) {
+      if (!(whole && build_ci_scales_mono(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp)))
+        b->cfg.math = FMD_MATH_FAST_MFMA;
+    } else if (!(b->cfg.mode == 2 && whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 &&
+                 stage_d_on_matrix_pipe(&b->taps, &b->kp)))
       b->cfg.math = FMD_MATH_FAST_MFMA_C;
   }
   if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {

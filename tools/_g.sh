@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5l
-( timeout 1200 python -m pytest tests/test_gpu_adversarial.py -m gpu -q 2>&1 | tail -40 ) > gpurun_out/r5l/adv_tests.txt; tail -25 gpurun_out/r5l/adv_tests.txt
-( timeout 600 python tools/adversarial_time.py 256 4 2>&1 | grep -v amdgpu | tail -6 ) > gpurun_out/r5l/adv_time.txt; cut -c1-600 gpurun_out/r5l/adv_time.txt
+mkdir -p gpurun_out/r5n
+( timeout 1500 python -m pytest tests -m gpu -x -q -k "mfma_d or default_family or quiet or adversarial" 2>&1 | tail -12 ) > gpurun_out/r5n/pytest.txt; tail -6 gpurun_out/r5n/pytest.txt
+FAMILIES="fast-mfma fast-mfma-d" bash tools/ab_math.sh r5n mono 2>&1 | grep -v amdgpu | tee gpurun_out/r5n/ab_mono.txt

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--math", default="fast")
-    ap.add_argument("--mode", default="stereo")
+    ap.add_argument("--mode", default="stereo", choices=["stereo", "mono", "nfm"])
     ap.add_argument("--data", default="fm")
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
@@ -30,14 +30,15 @@ def main():
     fam = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
            "fast-mfma-c": R.MATH_FAST_MFMA_C, "fast-mfma-d": R.MATH_FAST_MFMA_D}[a.math]
     cfg = R.wbfm_config(block_len=BL, math=fam,
-                        rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)
+                        **(dict(rate_in=25000, rate_out2=12500, mode=1) if a.mode == "nfm" else
+                           dict(rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)))
     b = R.BatchDemod(cfg, a.streams, device=0)
     import bench
     if a.data == "noise":
         g = torch.Generator(device=dev); g.manual_seed(12345)
         iq = torch.randint(0, 256, (a.streams, a.blocks, BL), dtype=torch.uint8, device=dev, generator=g)
     else:
-        iq = bench.synth_fm_iq(torch, dev, a.streams, a.blocks * BL // 2, 2.4e6, True, 12345).view(a.streams, a.blocks, BL)
+        iq = bench.synth_fm_iq(torch, dev, a.streams, a.blocks * BL // 2, 200e3 if a.mode == "nfm" else 2.4e6, a.mode != "nfm", 12345).view(a.streams, a.blocks, BL)
     pcm = torch.zeros((a.streams, a.blocks, b.pcm_stride), dtype=torch.int16, device=dev)
     lens = torch.zeros((a.streams, a.blocks), dtype=torch.int32, device=dev)
     prof = torch.zeros((a.streams * 64, 16), dtype=torch.int64, device=dev)
