@@ -74,10 +74,10 @@ def test_design_taps_equals_oracle():
     dict(block_len=100), dict(block_len=32), dict(size=91), dict(size=300), dict(mode=3),
     dict(rate_out2=200000),          # stereo beyond rate_out / 3
     dict(rate_out2=0, mode=2),
-    dict(math=5), dict(math=-1),
+    dict(math=6), dict(math=-1),
     # the +-1 LSB kernels evaluate the de-emphasis with powers of lambda: they need a contraction
     dict(math=R.MATH_FAST, deemph_lambda=1.0), dict(math=R.MATH_FAST_VALU, deemph_lambda=0.0),
-    dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5),
+    dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5), dict(math=R.MATH_FAST_MFMA_D, deemph_lambda=1.0),
 ])
 def test_bad_configs_are_rejected(bad):
     bad = dict(bad)
@@ -93,7 +93,7 @@ def test_bad_configs_are_rejected(bad):
 @pytest.mark.parametrize("ok", [
     dict(math=R.MATH_EXACT, deemph_lambda=1.0), dict(math=R.MATH_EXACT, deemph_lambda=0.0),   # the exact kernels take any lambda
     dict(math=R.MATH_FAST, deemph=False, deemph_lambda=1.0),                                  # ... and it is not read with de-emphasis off
-    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C),
+    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D),
 ])
 def test_good_configs_are_accepted(ok):
     lam = ok.pop("deemph_lambda", None)

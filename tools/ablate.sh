@@ -8,6 +8,6 @@ T=$(mktemp -d)
 cp -r $ROOT/rtl_fm_player_amd/csrc $T/csrc; mkdir -p $T/include; cp $ROOT/include/*.h $T/include/
 mkdir -p $T/x; mv $T/csrc $T/x/csrc; mkdir -p $T/x/../include
 make -s -C $T/x/csrc clean >/dev/null 2>&1 || true
-rm -f $T/x/csrc/*.o; make -s -C $T/x/csrc EXTRA_HIPFLAGS="-DFMD_ABLATE=$M -DFMD_FAST_WAVES=$W $FMD_EXTRA" INC="-I$ROOT/include -I. -I/opt/rocm/include" $FMD_MAKEVARS ../libfmdemod_mi355x.so 2>&1 | grep -E "error" || true
+rm -f $T/x/csrc/*.o; make -s -C $T/x/csrc EXTRA_HIPFLAGS="-DFMD_ABLATE=$M -DFMD_FAST_WAVES=$W $FMD_EXTRA" INC="-I$ROOT/include -I. -I/opt/rocm/include" ISA_LINT=true $FMD_MAKEVARS ../libfmdemod_mi355x.so 2>&1 | grep -E "error" || true
 mkdir -p $ROOT/.ablate; cp $T/x/libfmdemod_mi355x.so $ROOT/.ablate/lib_ab$M.so; rm -rf $T
 echo "built .ablate/lib_ab$M.so"
