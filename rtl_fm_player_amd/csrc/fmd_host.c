@@ -314,7 +314,7 @@ static int build_ci_scales_mono(const fmd_taps *t, int size, fmdk_params *k) {
 
 static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
   if (k->resample && k->mode == 1 && k->size == 128)       /* mono: the same selection rule (at most one emit among four samples) */
-    return (long long)k->fast >= 4LL * k->slow && k->emit_magic && k->tf_magic;
+    return (long long)k->fast >= 2LL * k->slow && k->emit_magic && k->tf_magic;   /* (one emit per four samples, or per pair: resample_mono_i8) */
   if (!(k->resample && k->mode == 2 && k->size == 90)) return 0;
   if ((long long)k->fast < 4LL * k->slow || !k->emit_magic || !k->tf_magic) return 0;
   double sm = 0.0, ss = 0.0;

@@ -189,7 +189,7 @@ def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R
     # stage D on the matrix pipe selects at most one emit among four consecutive samples: rate_out >= 4 rate_out2, else stage C alone
     for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_D), (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
                      (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA_D),
-                     (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
+                     (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA_D), (dict(rate_in=96000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA_D), (dict(rate_in=48000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
         for m in (R.MATH_FAST, R.MATH_FAST_MFMA_D):
             b = R.BatchDemod(R.wbfm_config(math=m, **kw), 1)
             assert b.math == want, (kw, m, b.math)
