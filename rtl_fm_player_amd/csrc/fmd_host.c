@@ -312,11 +312,35 @@ static int build_ci_scales_mono(const fmd_taps *t, int size, fmdk_params *k) {
   return 0;
 }
 
+/* What stage D's fixed-point form adds to a PCM value, in LSB (rms estimate), for n taps of the fm filter at scale 2^qf and the batch's
+ * PCM scale `coef` (volume x 32768): three independent terms -
+ *   the limb pairs left out (tap limb + sample limb >= 3: weight 2^-24 of the sum's scale c0 = 2^(12 - qf); 2 n products of two limbs
+ *     of rms 74 each),
+ *   the samples' rounding to 2^-20 (uniform: 2^-21 / sqrt 3 per sample, through the filter: x sqrt(sum h^2)),
+ *   the taps' rounding to 2^-qf (2^-(qf+1) / sqrt 3 per tap, n taps, samples of rms ~1.8 at most - a discriminator output uniform in +-pi).
+ * Stage D's output IS the PCM value before de-emphasis and scaling, so these are its error in LSB after x coef.  300 k stereo / mono:
+ * 0.004 at volume 0.4, 0.08 - 0.09 at volume 8 (max |difference| 1 LSB measured); 25 k narrow FM (largest tap 0.58: qf 23, c0 eight
+ * times the 300 k filters'): 0.035 at volume 0.4, 0.09 at 1, 0.26 at 3 (still 1 LSB at most in 262 144 values) and 0.70 at volume 8,
+ * where 3 LSB were measured (tools/low_amp_volume_scan.py, profiles/r5q_low_amp_volume_scan_before.txt).  Beyond 0.15 the
+ * configuration keeps stage D on the vector ALU: five standard deviations stay below one step. */
+static double stage_d_error_lsb(const float *fm, int n, int qf, float coef) {
+  double sh2 = 0.0;
+  for (int u = 0; u < n / 2; u++) sh2 += 2.0 * (double)fm[u] * (double)fm[u];
+  const double c0 = ldexp(1.0, 12 - qf);
+  const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * n) * 74.0 * 74.0;
+  const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
+  const double taps = sqrt((double)n) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
+  return fabs((double)coef) * sqrt(dropped * dropped + samples * samples + taps * taps);
+}
+#define FMD_STAGE_D_MAX_LSB 0.15
+
 static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
-  if (k->resample && k->mode == 1 && k->size == 128)       /* mono: the same selection rule (at most one emit among four samples) */
-    return (long long)k->fast >= 2LL * k->slow && k->emit_magic && k->tf_magic;   /* (one emit per four samples, or per pair: resample_mono_i8) */
+  if (k->resample && k->mode == 1 && k->size == 128)       /* mono: one emit per four samples, or per pair (resample_mono_i8) */
+    return (long long)k->fast >= 2LL * k->slow && k->emit_magic && k->tf_magic &&
+           stage_d_error_lsb(t->fm, 128, k->ci_qf[0], k->coef) <= FMD_STAGE_D_MAX_LSB;
   if (!(k->resample && k->mode == 2 && k->size == 90)) return 0;
   if ((long long)k->fast < 4LL * k->slow || !k->emit_magic || !k->tf_magic) return 0;
+  if (stage_d_error_lsb(t->fm, 90, k->ci_qf[0], k->coef) > FMD_STAGE_D_MAX_LSB) return 0;
   double sm = 0.0, ss = 0.0;
   for (int u = 0; u < 45; u++) { sm += 2.0 * fabs((double)t->fm[u]); ss += 2.0 * fabs((double)t->fs[u]); }
   return 3.1415927 * sm < 7.9 && 3.1415927 * ss < 7.9;

@@ -98,3 +98,35 @@ def test_quiet_input_many_streams_every_chunk(R, kind, fast_math):
     for got, want in run_both(R, CONFIGS["stereo_300k"], iq, nb, fast_math, n_streams=ns):
         worst = max(worst, int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()))
     assert worst <= 1, worst
+
+
+@pytest.mark.parametrize("volume", [3.0, 8.0])
+@pytest.mark.parametrize("amp", [1, 4, 20])
+@pytest.mark.parametrize("name", ["stereo_300k", "mono_300k", "nfm_25k"])
+def test_low_amplitude_at_high_volume(R, name, amp, volume, fast_math):
+    """The PCM step shrinks with `volume` (coef = volume x 32768, src/rtl_fm_player.c:717) while the fixed-point stages' errors do not:
+    samples just above the discriminator's origin threshold and the limb pairs the matrix-pipe filters leave out are largest in LSB here.
+    (Round 5 found narrow FM at volume 8 three LSB off through the matrix-pipe stage D: fmd_batch_create now estimates that stage's
+    error for the configuration - stage_d_error_lsb - and keeps it on the vector ALU beyond 0.15 LSB rms.)"""
+    nb, ns = 2, 4
+    rng = np.random.default_rng(4000 + amp)
+    iq = rng.integers(128 - amp, 128 + amp, ns * nb * BL, dtype=np.uint8)
+    kw = dict(CONFIGS[name], volume=volume)
+    worst = 0
+    for got, want in run_both(R, kw, iq, nb, fast_math, n_streams=ns):
+        worst = max(worst, int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()))
+    assert worst <= 1, worst
+
+
+def test_stage_d_stays_on_the_vector_alu_where_its_error_estimate_is_too_large(R):
+    """Narrow FM (25 k -> 12.5 k, 128 taps, largest tap 0.58): 0.035 / 0.09 / 0.26 / 0.70 LSB rms estimated at volume 0.4 / 1 / 3 / 8,
+    3 LSB measured at volume 8 through the matrix-pipe stage D; the limit is 0.15."""
+    for vol, want in ((0.4, R.MATH_FAST_MFMA_D), (1.0, R.MATH_FAST_MFMA_D), (3.0, R.MATH_FAST_MFMA), (8.0, R.MATH_FAST_MFMA)):
+        b = R.BatchDemod(R.wbfm_config(block_len=BL, math=R.MATH_FAST, volume=vol, **CONFIGS["nfm_25k"]), 1)
+        assert b.math == want, (vol, b.math)
+        b.close()
+    for vol in (0.4, 8.0):                                   # 300 k stereo / mono: 0.08 - 0.09 LSB at volume 8
+        for name in ("stereo_300k", "mono_300k"):
+            b = R.BatchDemod(R.wbfm_config(block_len=BL, math=R.MATH_FAST, volume=vol, **CONFIGS[name]), 1)
+            assert b.math == R.MATH_FAST_MFMA_D, (name, vol, b.math)
+            b.close()
