@@ -404,6 +404,19 @@ static void fill_params(fmd_batch *b) {
   }
   k->coef = c->volume * 32768.0f;               /* src/rtl_fm_player.c:717 */
   {
+    /* origin threshold of the fast discriminator (fmdk_params.org_thr): an isolated phase error e / rho of a sample of magnitude rho reaches
+     * the PCM as coef x (one tap of the filter behind the discriminator) x e / rho.  1e-3 was validated on narrow FM at volume 0.4
+     * (coef x largest tap = 13 107 x 0.58 = 7 600: tests/test_gpu_parity.py::test_fast_math_nfm_noise_next_to_the_origin); a larger
+     * product moves the threshold out in proportion, so that the PCM-level error at the threshold stays what it was there. */
+    float hmax = 0.f;
+    const float *first = (c->rate_out2 > 0 && c->mode != 0) ? b->taps.fm : NULL;      /* mode 0 / no resampler: the discriminator output goes out as it is */
+    if (first) { for (int i = 0; i < (c->size >> 1); i++) hmax = fmaxf(hmax, fabsf(first[i])); if (c->mode == 2) for (int i = 0; i < (c->size >> 1); i++) hmax = fmaxf(hmax, fabsf(b->taps.fs[i])); }
+    else hmax = 1.f;
+    const float scale = fabsf(k->coef) * hmax / 7600.0f;
+    k->org_thr = 1e-3f * (scale > 1.f ? (scale < 200.f ? scale : 200.f) : 1.f);
+    k->org_thr15 = 1.5f * k->org_thr;
+  }
+  {
     /* carrier_fast: an error e in (x, y) moves sin 2 atan2 by 2 |e| / r; times |vs|, one tap of the
      * second-stage low-pass (largest |fm|) and the PCM scale it must stay below a quarter LSB.
      * |e| ~ 1.5 eps with eps = 1e-7 the rounding difference between the fast and the reference

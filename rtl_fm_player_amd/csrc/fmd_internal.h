@@ -76,6 +76,11 @@ typedef struct fmdk_params {
    * taken with the scaled vs: car_inv_k2_q = 2^40 / K^2 (fmd_kernels.inc, mpx_tile_i8<MFD>, resample_tile_i8) */
   float ci_scale_q[3];
   float car_inv_k2_q;
+  /* fast kernels: decimated samples with |I| + |Q| <= org_thr are redone in the reference's arithmetic (stage B).  1e-3 where it was
+   * validated (narrow FM at the reference's default volume and everything with a larger PCM step per unit of discriminator error);
+   * grows with coef x (largest tap of the filter behind the discriminator) beyond that: the phase error of such a sample is
+   * (decimator difference) / magnitude and reaches the PCM through one tap */
+  float org_thr, org_thr15;      /* (and 1.5 x it: the lane-level pre-test on max(|cross|, |dot|)) */
 } fmdk_params;
 
 /* Launch the fused IQ->PCM kernel for n_streams streams.  Returns 0 or a

@@ -15,9 +15,10 @@ MODES = {"stereo": dict(rate_in=300000, rate_out2=48000, mode=2), "mono": dict(r
          "nfm": dict(rate_in=25000, rate_out2=12500, mode=1)}
 FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D}
 worst_all = 0
-for amp in (1, 2, 3, 4, 6, 10, 20):
+AMPS = [int(a) for a in os.environ.get("SCAN_AMPS", "1,2,3,4,6,10,20").split(",")]
+for amp in AMPS:
     rng = np.random.default_rng(1000 + amp)
-    iq = rng.integers(128 - amp, 128 + amp, NS * NB * BL, dtype=np.uint8).reshape(NS, NB, BL)
+    iq = rng.integers(max(0, 128 - amp), min(256, 128 + amp), NS * NB * BL, dtype=np.uint8).reshape(NS, NB, BL)
     for vol in (0.4, 1.0, 3.0, 8.0):
         for mname, kw in MODES.items():
             kw2 = dict(kw, volume=vol)
