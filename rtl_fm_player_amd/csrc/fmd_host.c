@@ -415,6 +415,7 @@ static void fill_params(fmd_batch *b) {
     const float scale = fabsf(k->coef) * hmax / 7600.0f;
     k->org_thr = 1e-3f * (scale > 1.f ? (scale < 200.f ? scale : 200.f) : 1.f);
     k->org_thr15 = 1.5f * k->org_thr;
+    k->pilot_pairs8 = fabsf(c->volume) >= 1.0f;      /* (mpx_tile_i8: eight limb pairs for the pilot filter instead of six) */
   }
   {
     /* carrier_fast: an error e in (x, y) moves sin 2 atan2 by 2 |e| / r; times |vs|, one tap of the

@@ -80,6 +80,7 @@ typedef struct fmdk_params {
    * validated (narrow FM at the reference's default volume and everything with a larger PCM step per unit of discriminator error);
    * grows with coef x (largest tap of the filter behind the discriminator) beyond that: the phase error of such a sample is
    * (decimator difference) / magnitude and reaches the PCM through one tap */
+  int32_t pilot_pairs8;          /* matrix-pipe stage C: the pilot filter's class-3 limb pairs too (volume >= 1: the carrier's accuracy in LSB scales with it) */
   float org_thr, org_thr15;      /* (and 1.5 x it: the lane-level pre-test on max(|cross|, |dot|)) */
 } fmdk_params;
 
