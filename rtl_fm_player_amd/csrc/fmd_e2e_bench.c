@@ -11,7 +11,7 @@
  * plain memcpy of the same transfers into pinned memory and into ordinary memory.
  *
  *   fmd_e2e_bench [-S streams=64] [-B blocks per job=16] [-J jobs=20] [-T feeder threads=16] [-m mode 2|1] [-e]
- *                 [-i rate_in=300000] [-o rate_out2=48000] [-z lpr.size] [-M math code 0..4 (fmdemod_mi355x.h)] [-W stall seconds=60]
+ *                 [-i rate_in=300000] [-o rate_out2=48000] [-z lpr.size] [-M math code 0..5 (fmdemod_mi355x.h)] [-W stall seconds=60]
  * prints ONE JSON line on stdout (the configuration it really ran is part of it).
  */
 #define _GNU_SOURCE
