@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh r14q_stereo 2>&1 | tail -1
-bash tools/profile_round.sh r14q_mono --mode mono 2>&1 | tail -1
-bash tools/profile_round.sh r14q_nfm --mode nfm 2>&1 | tail -1
-mkdir -p gpurun_out/r14
-for m in stereo mono nfm; do python tools/stage_profile.py --mode $m 2>/dev/null > gpurun_out/r14/stage_$m.json; done
-python bench.py --steps 20 --warmup 5 > gpurun_out/r14/bench_default_line.json 2>/dev/null
-python bench.py --steps 100 --warmup 10 --math exact --no-cpu --no-e2e --no-extra 2>/dev/null > gpurun_out/r14/bench_exact_line.json
+mkdir -p gpurun_out/r14s
+for s in $(seq 65 104); do timeout 600 python tools/fuzz_parity.py 400 $s 2>&1 | grep -v amdgpu | tail -1; done > gpurun_out/r14s/fuzz_soak.txt
+for s in $(seq 1 10); do FUZZ_VOLUMES=1 timeout 600 python tools/fuzz_parity.py 400 $s 2>&1 | grep -v amdgpu | tail -1; done > gpurun_out/r14s/fuzz_volumes.txt
+awk '{m+=$NF; n+=$4} END {print "fuzz: cases", n, "mismatches", m}' gpurun_out/r14s/fuzz_soak.txt
+awk '{m+=$NF; n+=$4} END {print "fuzz with the volume draw: cases", n, "mismatches", m}' gpurun_out/r14s/fuzz_volumes.txt
