@@ -251,6 +251,9 @@ int fmd_batch_n_streams(const fmd_batch *b);
 /* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA, FMD_MATH_FAST_MFMA_C or _MFMA_D (FMD_MATH_FAST
  * in the configuration resolves to one of the last four at creation; a named family the configuration cannot run resolves likewise). */
 int fmd_batch_math(const fmd_batch *b);
+/* The same question without a device or a batch: the family fmd_batch_create would run for this configuration (and these taps; NULL:
+ * fmd_design_taps), or a negative status for a configuration it would refuse. */
+int fmd_config_family(const fmd_config *cfg, const fmd_taps *taps);
 /* How a launch is cut into time chunks (one worker wavefront each; results do not depend on it - the tests hold the
  * library to that through this call): workers_per_cu > 0 = cut until the grid offers that many workers per CU,
  * 0 = the kernels' own figure (default), < 0 = never cut (one worker per stream). */

@@ -21,6 +21,7 @@ from .capi import (  # noqa: F401
     FmdStreamState,
     FmdTaps,
     build_library,
+    config_family,
     design_taps,
     device_count,
     lib,

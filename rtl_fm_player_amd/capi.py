@@ -98,7 +98,7 @@ _EXPORTS = [
     "init_u8_f32_table", "init_lp_f32", "init_lp_real_f32", "deinit_lp_real_f32", "demod_init",
     "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release",
     "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
-    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_batch_set_time_split", "fmd_batch_run_device", "fmd_batch_run_device_debug",
+    "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_config_family", "fmd_batch_set_time_split", "fmd_batch_run_device", "fmd_batch_run_device_debug",
     "fmd_batch_sync", "fmd_batch_wait_stream", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
     "fmd_device_count", "fmd_ingest_create", "fmd_ingest_destroy", "fmd_ingest_callback",
@@ -140,6 +140,7 @@ def lib():
     L.fmd_batch_pcm_stride.argtypes = [vp]
     L.fmd_batch_n_streams.argtypes = [vp]
     L.fmd_batch_math.argtypes = [vp]
+    L.fmd_config_family.argtypes = [C.POINTER(FmdConfig), vp]
     L.fmd_batch_set_time_split.argtypes = [vp, C.c_int]
     L.fmd_batch_run_device.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.fmd_batch_run_device_debug.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(FmdDebugTaps)]
@@ -209,6 +210,13 @@ def design_taps(cfg):
     t = FmdTaps()
     _check(lib().fmd_design_taps(C.byref(cfg), C.byref(t)), "fmd_design_taps")
     return t
+
+
+def config_family(cfg, taps=None):
+    """The kernel family fmd_batch_create would run for this configuration (needs no device); raises FmdError for one it refuses."""
+    rc = lib().fmd_config_family(C.byref(cfg), C.byref(taps) if taps is not None else None)
+    _check(rc if rc < 0 else 0, "fmd_config_family")
+    return rc
 
 
 def _ptr(x):

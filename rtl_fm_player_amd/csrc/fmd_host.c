@@ -512,22 +512,10 @@ static void fill_params(fmd_batch *b) {
   k->pcm_stride = b->pcm_stride;
 }
 
-int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *taps, int n_streams,
-                     int device) {
-  if (!out) return fail(FMD_E_ARG, "out is NULL");
-  *out = NULL;
-  int rc = check_config(cfg);
-  if (rc) return rc;
-  if (n_streams <= 0) return fail(FMD_E_ARG, "n_streams must be positive");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(FMD_E_NODEVICE, "no HIP device: the MI355X path has no CPU fallback");
-  if (device < 0) HIP_TRY(hipGetDevice(&device));
-  if (device >= ndev) return fail(FMD_E_ARG, "device %d out of range (%d devices)", device, ndev);
-  HIP_TRY(hipSetDevice(device));
-
-  fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
-  if (!b) return fail(FMD_E_NOMEM, "out of host memory");
+/* Configuration -> kernel family and launch parameters (b->cfg.math, b->taps, b->kp): everything fmd_batch_create decides before it touches
+ * the device.  FMD_MATH_FAST and the named +-1 LSB families resolve downwards to what the configuration can run. */
+static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *taps) {
+  int rc = 0;
   b->cfg = *cfg;
   /* FMD_MATH_FAST = the fastest +-1 LSB kernel family for the configuration (a caller who wants a particular one names it in
    * fmd_config.math; FMD_MFMA is read by tuning builds only) */
@@ -538,10 +526,8 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
                                                      run resolves downwards, see below) */
     b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : FMD_MATH_FAST_MFMA_D;
   }
-  b->n_streams = n_streams;
-  b->device = device;
   if (taps) b->taps = *taps;
-  else if ((rc = fmd_design_taps(cfg, &b->taps))) { free(b); return rc; }
+  else if ((rc = fmd_design_taps(cfg, &b->taps))) return rc;
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
   if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
@@ -565,10 +551,45 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
   if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
-      if (cfg->math != FMD_MATH_FAST) { free(b); return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }
+      if (cfg->math != FMD_MATH_FAST) { return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }
       b->cfg.math = FMD_MATH_FAST_VALU;
     }
   }
+
+  return FMD_OK;
+}
+
+int fmd_config_family(const fmd_config *cfg, const fmd_taps *taps) {
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
+  if (!b) return fail(FMD_E_NOMEM, "out of host memory");
+  b->n_streams = 1;
+  rc = resolve_family(b, cfg, taps);
+  const int fam = b->cfg.math;
+  free(b);
+  return rc ? rc : fam;
+}
+
+int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *taps, int n_streams,
+                     int device) {
+  if (!out) return fail(FMD_E_ARG, "out is NULL");
+  *out = NULL;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (n_streams <= 0) return fail(FMD_E_ARG, "n_streams must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMD_E_NODEVICE, "no HIP device: the MI355X path has no CPU fallback");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= ndev) return fail(FMD_E_ARG, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
+  if (!b) return fail(FMD_E_NOMEM, "out of host memory");
+  b->n_streams = n_streams;
+  b->device = device;
+  if ((rc = resolve_family(b, cfg, taps))) { free(b); return rc; }
 
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||

@@ -104,6 +104,48 @@ def test_good_configs_are_accepted(ok):
     assert R.lib().fmd_design_taps(C.byref(cfg), C.byref(t)) == 0
 
 
+@pytest.mark.parametrize("kw,want", [
+    # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2: stages A, C, D on the matrix pipe
+    (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_D"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_D"),
+    (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_D"),
+    # rate_out < 4 rate_out2: the selection of stage D does not apply - stage C alone
+    (dict(rate_in=171000, rate_out2=44100, mode=2), "MFMA_C"),
+    # other filter sizes, ragged tiles: stage A only
+    (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=2, block_len=16000), "MFMA"),
+    # 128-tap mono / narrow FM: stage D on the matrix pipe at rate_out >= 2 rate_out2 ...
+    (dict(rate_in=300000, rate_out2=48000, mode=1), "MFMA_D"), (dict(rate_in=25000, rate_out2=12500, mode=1), "MFMA_D"),
+    (dict(rate_in=96000, rate_out2=32000, mode=1), "MFMA_D"), (dict(rate_in=48000, rate_out2=32000, mode=1), "MFMA"),
+    (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), "MFMA"),
+    # ... while its fixed-point error estimate stays below 0.15 LSB: narrow FM's filter (largest tap 0.58) at volume 3 and 8 does not
+    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=1.0), "MFMA_D"), (dict(rate_in=25000, rate_out2=12500, mode=1, volume=3.0), "MFMA"),
+    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=8.0), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=1, volume=8.0), "MFMA_D"),
+    # mode 0 / no resampler
+    (dict(rate_in=300000, rate_out2=0, mode=1), "MFMA"),
+])
+def test_family_resolution_needs_no_device(kw, want):
+    """What FMD_MATH_FAST (and the named family) resolves to is decided on the host before the device is touched (fmd_config_family):
+    the rules of DESIGN.md section 1 / 2a, checked here without a GPU."""
+    code = {"MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA, "VALU": R.MATH_FAST_VALU}[want]
+    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_D):
+        assert R.config_family(R.wbfm_config(math=m, **kw)) == code, (kw, m)
+    assert R.config_family(R.wbfm_config(math=R.MATH_EXACT, **kw)) == R.MATH_EXACT
+    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_VALU, **kw)) == R.MATH_FAST_VALU
+
+
+def test_family_resolution_with_a_callers_taps():
+    """Taps the fixed-point forms cannot hold resolve downwards (FMD_MATH_FAST) or are refused (a named matrix-pipe family)."""
+    cfg = R.wbfm_config(math=R.MATH_FAST, rate_in=300000, rate_out2=48000, mode=2)
+    t = R.design_taps(cfg)
+    for k in range(45):
+        t.fs[k] = 8355711.0 / 2 ** 23               # every limb at its maximum: the float-accumulator bound of stage C fails
+    assert R.config_family(cfg, t) == R.MATH_FAST_MFMA
+    t = R.design_taps(cfg)
+    t.fb[3] = 0.2                                   # beyond the 26-bit form of the decimator taps
+    assert R.config_family(cfg, t) == R.MATH_FAST_VALU
+    with pytest.raises(R.FmdError):
+        R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA, rate_in=300000, rate_out2=48000, mode=2), t)
+
+
 def test_create_without_device_fails_loudly():
     if R.device_count() > 0:
         pytest.skip("a HIP device is present")
