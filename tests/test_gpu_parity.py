@@ -447,6 +447,46 @@ def test_drop_in_keeps_the_stream_across_a_config_change(R, lcg40):
     L.deinit_lp_real_f32(C.byref(d))
 
 
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_launches_captured_in_a_hip_graph(R, math):
+    """One block per launch is the reference's real-time cadence (src/rtl_fm_player.c:863-889); a caller who wants that without the per-launch
+    host cost captures the launches into a hipGraph on its own stream and replays it.  The library then launches plainly (no timing events
+    on the dispatch packet: a captured stream) and its state ping-pong must come out where it went in: an EVEN number of
+    launches per graph.  Two one-block launches per graph, four replays, eight streams, against the oracle."""
+    import torch
+    from oracle import OracleStream, lcg_bytes
+    S, kw = 8, CONFIGS["stereo_300k"]
+    dev = torch.device("cuda:0")
+    iq_all = np.stack([lcg_bytes(8 * BL, 100 + s)[0] for s in range(S)]).reshape(S, 8, BL)
+    b = R.BatchDemod(R.wbfm_config(block_len=BL, math=R.MATH_EXACT if math == "exact" else R.MATH_FAST, **kw), S)
+    bufs = [(torch.zeros((S, 1, BL), dtype=torch.uint8, device=dev), torch.zeros((S, 1, b.pcm_stride), dtype=torch.int16, device=dev),
+             torch.zeros((S, 1), dtype=torch.int32, device=dev)) for _ in range(2)]
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=st):
+        for iq, pcm, lens in bufs:
+            b.run_device(iq, 1, pcm, lens, hip_stream=st.cuda_stream)
+    b.reset()
+    out = [[] for _ in range(S)]
+    for k in range(0, 8, 2):
+        for j, (iq, _, _) in enumerate(bufs):
+            iq.copy_(torch.from_numpy(iq_all[:, k + j:k + j + 1].copy()))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for s in range(S):
+            for _, pcm, lens in bufs:
+                out[s].append(pcm[s, 0, :int(lens[s, 0])].cpu().numpy().copy())
+    for s in range(S):
+        want, _ = OracleStream(**kw).run(iq_all[s].reshape(-1), BL)
+        got = np.concatenate(out[s])
+        assert got.size == want.size
+        d = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
+        assert d <= (0 if math == "exact" else 1), (s, d)
+    b.close()
+
+
 def test_ingest_callback_and_pump(R):
     """rtlsdr_read_async-shaped ingest: odd-sized callback buffers -> pinned ring -> batch."""
     from oracle import OracleStream, lcg_bytes
