@@ -1,0 +1,72 @@
+// What an instruction costs at the package power cap: every SIMD of the chip streams ONE instruction class (W waves per SIMD), the host counts
+// wave-instructions per second; tools/power_price.sh samples rocm-smi beside it.  energy per wave-instruction <= package power / rate (an upper
+// bound: the package draws ~280 W doing nothing).   hipcc --offload-arch=gfx950 -O2 -o power_price power_price.hip ; ./power_price <kind> [waves per SIMD] [seconds]
+//   kinds: mfma (v_mfma_i32_16x16x64_i8), fma (v_fma_f32), pkfma (v_pk_fma_f32), mix (1 MFMA : 5 v_fma_f32 : the stereo kernel's ratio), nop (s_nop)
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int UNROLL = 16;
+template <int KIND>
+__global__ __launch_bounds__(256) void k(int iters, float *sink) {
+  i4 a = {(int)threadIdx.x, 2, 3, 4}, b = {5, 6, (int)blockIdx.x, 8};
+  i4 acc[4] = {{0, 0, 0, 0}, {1, 1, 1, 1}, {2, 2, 2, 2}, {3, 3, 3, 3}};
+  float f[8];
+  f2 p[4];
+  for (int i = 0; i < 8; i++) f[i] = (float)(threadIdx.x + i) * 1e-3f;
+  for (int i = 0; i < 4; i++) p[i] = f2{f[i], f[i + 4]};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      if constexpr (KIND == 0) acc[u & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[u & 3], 0, 0, 0);
+      if constexpr (KIND == 1) f[u & 7] = __builtin_fmaf(f[u & 7], 1.0001f, 0.5f);
+      if constexpr (KIND == 2) p[u & 3] = __builtin_elementwise_fma(p[u & 3], f2{1.0001f, 0.9999f}, f2{0.5f, 0.25f});
+      if constexpr (KIND == 3) {
+        if ((u % 6) == 0) acc[(u / 6) & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[(u / 6) & 3], 0, 0, 0);
+        else f[u & 7] = __builtin_fmaf(f[u & 7], 1.0001f, 0.5f);
+      }
+      if constexpr (KIND == 4) asm volatile("s_nop 0");
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; i++) s += f[i];
+  for (int i = 0; i < 4; i++) s += p[i].x + p[i].y + (float)(acc[i].x + acc[i].y + acc[i].z + acc[i].w);
+  if (s == 12345.678f) sink[0] = s;
+}
+int main(int argc, char **argv) {
+  const char *kind = argc > 1 ? argv[1] : "mfma";
+  const int W = argc > 2 ? atoi(argv[2]) : 2;
+  const double seconds = argc > 3 ? atof(argv[3]) : 6.0;
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount;
+  const int blocks = cus * W;                 /* 256 threads = 4 waves = one per SIMD; W blocks per CU */
+  float *sink;
+  (void)hipMalloc(&sink, 4);
+  const int iters = 20000;
+  auto launch = [&]() {
+    if (!strcmp(kind, "mfma")) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "fma")) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "pkfma")) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "mix")) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+  };
+  for (int i = 0; i < 3; i++) launch();
+  (void)hipDeviceSynchronize();
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  double el = 0;
+  while (el < seconds) {
+    for (int i = 0; i < 4; i++) launch();
+    (void)hipDeviceSynchronize();
+    launches += 4;
+    el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  const double winstr = (double)launches * blocks * 4 * (double)iters * UNROLL;      /* wave-instructions of the class */
+  printf("kind %s W %d: %.3e wave-instructions/s over %.1f s (%d CUs); cycles per instruction and SIMD at 2.4 GHz: %.2f\n", kind, W, winstr / el, el, cus,
+         2.4e9 * el / (winstr / (cus * 4.0)));
+  return 0;
+}
