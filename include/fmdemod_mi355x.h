@@ -165,8 +165,8 @@ void fmd_demod_release(struct demod_state *d);
 
 /* arithmetic contract */
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
-#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_D
-                             (or _C) for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
+#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_E
+                             (or _D, _C) for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
                              a caller who wants a particular family names it here instead (the library reads no environment
                              variable for this).  fmd_batch_math() says what a batch runs.  Sharing the device with other
                              MFMA kernels: one packed-fp32 instruction form computed wrong results beside them (round 3); it is
@@ -185,6 +185,12 @@ void fmd_demod_release(struct demod_state *d);
                                   matrix pipe from int8 limbs of {L+R, (L-R) x carrier}, the emit instants selected afterwards
                                   (needs rate_out >= 4 rate_out2): the default of FMD_MATH_FAST where it applies; other
                                   configurations run FMD_MATH_FAST_MFMA_C / _MFMA under this name */
+#define FMD_MATH_FAST_MFMA_E 6 /* ... with the L+R channel's two low-passes (src/rtl_fm_player.c:545, :588: the fm filter over the
+                                  discriminator ring, then again over the bm ring at the emit instants) as ONE 179-tap filter fm * fm
+                                  over the discriminator output - a linear chain needs no intermediate: 12 matrix instructions, a
+                                  join, a limb split and three limb arrays per tile less.  90-tap stereo where _MFMA_D applies: the
+                                  default of FMD_MATH_FAST there since round 5; 128-tap mono and everything else run what
+                                  FMD_MATH_FAST_MFMA_D runs */
 
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
@@ -198,7 +204,7 @@ typedef struct fmd_config {
   float volume;           /* demod_state.volume                                */
   int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
                           /* multiple of 16, >= 64                             */
-  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D) */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D / _MFMA_E) */
 } fmd_config;
 
 /* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /
@@ -248,8 +254,8 @@ void fmd_batch_destroy(fmd_batch *b);
 /* int16 slots per (stream, block) in the PCM buffer (multiple of 8). */
 int fmd_batch_pcm_stride(const fmd_batch *b);
 int fmd_batch_n_streams(const fmd_batch *b);
-/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA, FMD_MATH_FAST_MFMA_C or _MFMA_D (FMD_MATH_FAST
- * in the configuration resolves to one of the last four at creation; a named family the configuration cannot run resolves likewise). */
+/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA, FMD_MATH_FAST_MFMA_C, _MFMA_D or _MFMA_E (FMD_MATH_FAST
+ * in the configuration resolves to one of the last five at creation; a named family the configuration cannot run resolves likewise). */
 int fmd_batch_math(const fmd_batch *b);
 /* The same question without a device or a batch: the family fmd_batch_create would run for this configuration (and these taps; NULL:
  * fmd_design_taps), or a negative status for a configuration it would refuse. */

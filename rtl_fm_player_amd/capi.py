@@ -15,7 +15,8 @@ MATH_FAST_VALU = 2     # +-1 LSB, vector ALU only
 MATH_FAST_MFMA = 3     # +-1 LSB, /8 decimator on the matrix pipe
 MATH_FAST_MFMA_C = 4   # ... and the three 90-tap stereo MPX filters there too (int8 limbs)
 MATH_FAST_MFMA_D = 5   # ... and the stereo resampler's second-stage low-pass (at every sample, emit instants selected)
-FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C, MATH_FAST_MFMA_D)
+MATH_FAST_MFMA_E = 6   # ... with the L+R chain (fm over the discriminator ring, fm again over the bm ring) as one 179-tap filter fm * fm
+FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C, MATH_FAST_MFMA_D, MATH_FAST_MFMA_E)
 MAXIMUM_BUF_LENGTH = 16 * 16384
 
 

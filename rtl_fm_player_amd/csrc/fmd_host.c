@@ -133,7 +133,7 @@ static int check_config(const fmd_config *c) {
   if (c->mode < 0 || c->mode > 2) return fail(FMD_E_ARG, "lpr.mode must be 0, 1 or 2");
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
-  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_D)
+  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_E)
     return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_C");
   /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
    * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
@@ -346,6 +346,52 @@ static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
   return 3.1415927 * sm < 7.9 && 3.1415927 * ss < 7.9;
 }
 
+/* FMD_MATH_FAST_MFMA_E: the L+R chain of the stereo path as ONE filter.  The reference low-passes the discriminator output with fm into the
+ * bm ring at every sample (src/rtl_fm_player.c:545, :560) and low-passes that ring with fm again at the emit instants (:588): with no
+ * non-linear step between them the two are the 179-tap filter g = fm * fm over the discriminator output.  g in double from the float taps,
+ * T_g = round(g 2^qf) in three balanced int8 limbs like every filter of the matrix-pipe stages; the same bound on the weight classes
+ * (accumulators read as floats) and the same error estimate as stage D's (one quantisation of the samples instead of two).  The kernel's
+ * window holds 192 samples for 16 shifted rows: taps 177 and 178 (fm[0]^2 and 2 fm[0] fm[1]) are missing in row 0, tap 178 in row 1 -
+ * their weight is part of the estimate. */
+static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
+  if (k->size != 90) return -1;
+  double g[179];
+  for (int u = 0; u < 179; u++) {
+    double a = 0.0;
+    for (int i = 0; i < 90; i++) {
+      const int j = u - i;
+      if (j < 0 || j >= 90) continue;
+      a += (double)t->fm[i < 45 ? i : 89 - i] * (double)t->fm[j < 45 ? j : 89 - j];
+    }
+    g[u] = a;
+  }
+  double mx = 0.0, sh2 = 0.0;
+  for (int u = 0; u < 179; u++) { mx = fmax(mx, fabs(g[u])); sh2 += g[u] * g[u]; }
+  if (!(mx > 0.0) || !isfinite(mx)) return -1;
+  int qf = 40;
+  while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
+  if (qf < 8) return -1;
+  double sum_abs = 0.0;
+  for (int u = 0; u < 179; u++) {
+    const long long E = llround(g[u] * ldexp(1.0, qf));
+    const unsigned q = ((unsigned)(int)E + 0x808080u) ^ 0x808080u;
+    for (int l = 0; l < 3; l++) sum_abs += fabs((double)(signed char)(q >> (8 * (2 - l))));
+    if (u < 90) k->gq[u] = (int32_t)E;
+  }
+  if (128.0 * sum_abs >= 4194304.0 - 65536.0) return -1;
+  /* error estimate in LSB (stage_d_error_lsb's three terms for 179 taps) + the two end taps rows 0 and 1 lack, at full deviation */
+  const double c0 = ldexp(1.0, 12 - qf);
+  const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * 179.0) * 74.0 * 74.0;
+  const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
+  const double taps = sqrt(179.0) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
+  const double ends = (fabs(g[177]) + fabs(g[178])) * 1.8;
+  if (fabs((double)k->coef) * (sqrt(dropped * dropped + samples * samples + taps * taps) + ends) > FMD_STAGE_D_MAX_LSB) return -1;
+  k->g_qf = qf;
+  k->g_scale = (float)ldexp(1.0, 12 - qf);
+  k->g_unit = (float)ldexp(1.0, -qf);
+  return 0;
+}
+
 static void fill_params(fmd_batch *b) {
   fmdk_params *k = &b->kp;
   const fmd_config *c = &b->cfg;
@@ -521,15 +567,17 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
    * fmd_config.math; FMD_MFMA is read by tuning builds only) */
   if (b->cfg.math == FMD_MATH_FAST) {
     const char *e_m = tuning_env("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 3;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3 (default):
+    const int sel = e_m ? atoi(e_m) : 4;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3 (default):
                                                      stages A, C and D (90-tap stereo with whole tiles; what a configuration cannot
                                                      run resolves downwards, see below) */
-    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : FMD_MATH_FAST_MFMA_D;
+    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : sel == 3 ? FMD_MATH_FAST_MFMA_D : FMD_MATH_FAST_MFMA_E;
   }
   if (taps) b->taps = *taps;
   else if ((rc = fmd_design_taps(cfg, &b->taps))) return rc;
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
+  const int want_e = b->cfg.math == FMD_MATH_FAST_MFMA_E;
+  if (want_e) b->cfg.math = FMD_MATH_FAST_MFMA_D;   /* _E is _D with the L+R chain as one filter: the same conditions first */
   if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
     /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone.
      * 128-tap mono: stage D on the matrix pipe under the same name (there is no stage C), otherwise stage A alone. */
@@ -540,6 +588,8 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
     } else if (!(b->cfg.mode == 2 && whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 &&
                  stage_d_on_matrix_pipe(&b->taps, &b->kp)))
       b->cfg.math = FMD_MATH_FAST_MFMA_C;
+    else if (want_e && b->cfg.mode == 2 && build_lr_composite(&b->taps, &b->kp) == 0)
+      b->cfg.math = FMD_MATH_FAST_MFMA_E;
   }
   if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {
     /* stage C on the matrix pipe: 90-tap stereo with whole tiles (block_len a multiple of 8192 bytes); anything else runs the
@@ -548,7 +598,8 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
           build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0))
       b->cfg.math = FMD_MATH_FAST_MFMA;
   }
-  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D) {
+  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D ||
+      b->cfg.math == FMD_MATH_FAST_MFMA_E) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
       if (cfg->math != FMD_MATH_FAST) { return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }

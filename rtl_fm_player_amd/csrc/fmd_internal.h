@@ -80,6 +80,12 @@ typedef struct fmdk_params {
    * validated (narrow FM at the reference's default volume and everything with a larger PCM step per unit of discriminator error);
    * grows with coef x (largest tap of the filter behind the discriminator) beyond that: the phase error of such a sample is
    * (decimator difference) / magnitude and reaches the PCM through one tap */
+  /* FMD_MATH_FAST_MFMA_E: the L+R chain as one filter g = fm * fm (179 taps, symmetric) over the discriminator output: T_g = round(g 2^g_qf)
+   * in three balanced int8 limbs, gq[u] = T_g[u] = T_g[178 - u] for u <= 89; y = g_scale (A0 + A1 2^-8 + A2 2^-16), g_scale = 2^(12 - g_qf);
+   * g_unit = 2^-g_qf turns a T_g into its tap for the cold paths (fmd_kernels.inc: mpx_tile_i8e, lr_head_fix) */
+  int32_t gq[90];
+  int32_t g_qf;
+  float g_scale, g_unit;
   int32_t pilot_pairs8;          /* matrix-pipe stage C: the pilot filter's class-3 limb pairs too (volume >= 1: the carrier's accuracy in LSB scales with it) */
   float org_thr, org_thr15;      /* (and 1.5 x it: the lane-level pre-test on max(|cross|, |dot|)) */
 } fmdk_params;

@@ -20,11 +20,12 @@ def lcg40():
     return buf
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma_c", "mfma_d"])
+@pytest.fixture(params=["valu", "mfma", "mfma_c", "mfma_d", "mfma_e"])
 def fast_math(request):
     """The +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST resolves to for
     mono / NFM / generic filter sizes), and stages A + C on the matrix pipe (what it resolves to for 90-tap stereo with whole tiles;
     other configurations run the stage-A family under that name), and stages A + C + D (the default for 90-tap stereo at
-    rate_out >= 4 rate_out2)."""
+    rate_out >= 4 rate_out2 up to round 5's first half), and the same with the L+R chain as one composite filter (mfma_e: today's default there;
+    mono and everything else run what mfma_d runs under that name)."""
     import rtl_fm_player_amd as R
-    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D}[request.param]
+    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E}[request.param]

@@ -74,10 +74,11 @@ def test_design_taps_equals_oracle():
     dict(block_len=100), dict(block_len=32), dict(size=91), dict(size=300), dict(mode=3),
     dict(rate_out2=200000),          # stereo beyond rate_out / 3
     dict(rate_out2=0, mode=2),
-    dict(math=6), dict(math=-1),
+    dict(math=7), dict(math=-1),
     # the +-1 LSB kernels evaluate the de-emphasis with powers of lambda: they need a contraction
     dict(math=R.MATH_FAST, deemph_lambda=1.0), dict(math=R.MATH_FAST_VALU, deemph_lambda=0.0),
     dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5), dict(math=R.MATH_FAST_MFMA_D, deemph_lambda=1.0),
+    dict(math=R.MATH_FAST_MFMA_E, deemph_lambda=1.0),
 ])
 def test_bad_configs_are_rejected(bad):
     bad = dict(bad)
@@ -93,7 +94,7 @@ def test_bad_configs_are_rejected(bad):
 @pytest.mark.parametrize("ok", [
     dict(math=R.MATH_EXACT, deemph_lambda=1.0), dict(math=R.MATH_EXACT, deemph_lambda=0.0),   # the exact kernels take any lambda
     dict(math=R.MATH_FAST, deemph=False, deemph_lambda=1.0),                                  # ... and it is not read with de-emphasis off
-    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D),
+    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D), dict(math=R.MATH_FAST_MFMA_E),
 ])
 def test_good_configs_are_accepted(ok):
     lam = ok.pop("deemph_lambda", None)
@@ -105,8 +106,10 @@ def test_good_configs_are_accepted(ok):
 
 
 @pytest.mark.parametrize("kw,want", [
-    # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2: stages A, C, D on the matrix pipe
-    (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_D"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_D"),
+    # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2: stages A, C, D on the matrix pipe, the L+R chain as one composite filter ...
+    (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_E"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_E"),
+    (dict(rate_in=240000, rate_out2=48000, mode=2, volume=3.0), "MFMA_E"),
+    # ... while the composite's error estimate (its two end taps are missing in two of sixteen rows) stays below 0.15 LSB: not at volume 8
     (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_D"),
     # rate_out < 4 rate_out2: the selection of stage D does not apply - stage C alone
     (dict(rate_in=171000, rate_out2=44100, mode=2), "MFMA_C"),
@@ -125,9 +128,11 @@ def test_good_configs_are_accepted(ok):
 def test_family_resolution_needs_no_device(kw, want):
     """What FMD_MATH_FAST (and the named family) resolves to is decided on the host before the device is touched (fmd_config_family):
     the rules of DESIGN.md section 1 / 2a, checked here without a GPU."""
-    code = {"MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA, "VALU": R.MATH_FAST_VALU}[want]
-    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_D):
+    code = {"MFMA_E": R.MATH_FAST_MFMA_E, "MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA, "VALU": R.MATH_FAST_VALU}[want]
+    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_E):
         assert R.config_family(R.wbfm_config(math=m, **kw)) == code, (kw, m)
+    # the family of round 5's first half, named: what it was
+    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_D, **kw)) == (R.MATH_FAST_MFMA_D if want == "MFMA_E" else code), kw
     assert R.config_family(R.wbfm_config(math=R.MATH_EXACT, **kw)) == R.MATH_EXACT
     assert R.config_family(R.wbfm_config(math=R.MATH_FAST_VALU, **kw)) == R.MATH_FAST_VALU
 

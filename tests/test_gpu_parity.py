@@ -184,15 +184,15 @@ def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R
     import torch
     cfg_kw = CONFIGS["stereo_300k"]
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **cfg_kw), 1)
-    assert b.math == R.MATH_FAST_MFMA_D
+    assert b.math == R.MATH_FAST_MFMA_E
     b.close()
     # stage D on the matrix pipe selects at most one emit among four consecutive samples: rate_out >= 4 rate_out2, else stage C alone
-    for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_D), (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
+    for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_E), (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
                      (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA_D),
                      (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA_D), (dict(rate_in=96000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA_D), (dict(rate_in=48000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
-        for m in (R.MATH_FAST, R.MATH_FAST_MFMA_D):
+        for m in (R.MATH_FAST, R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_D):   # (_MFMA_D named: what it was before the composite L+R filter)
             b = R.BatchDemod(R.wbfm_config(math=m, **kw), 1)
-            assert b.math == want, (kw, m, b.math)
+            assert b.math == (R.MATH_FAST_MFMA_D if (m == R.MATH_FAST_MFMA_D and want == R.MATH_FAST_MFMA_E) else want), (kw, m, b.math)
             b.close()
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, block_len=16 * 1000, **cfg_kw), 1)      # ragged tiles: stage A only
     assert b.math == R.MATH_FAST_MFMA
@@ -229,6 +229,23 @@ def test_carried_state_matches_oracle(R, lcg40):
     assert list(a.tb) == list(g.tb)
     for f in ("br", "bm", "bs"):
         assert list(getattr(a, f))[:90] == list(getattr(g, f))[:90], f
+
+
+@pytest.mark.parametrize("name", ["stereo_300k", "stereo_192k"])
+def test_fast_carried_rings_match_the_oracle(R, lcg40, name, fast_math):
+    """What a +-1 LSB launch leaves in the br / bm / bs rings (the drop-in surface mirrors them into the caller's struct lp_real) against the
+    reference's rings: br in the reference's own bits where the hand-over recomputes it, bm and bs to a few steps of the 2^-20 grid the
+    matrix-pipe stages keep them on.  FMD_MATH_FAST_MFMA_E keeps NO bm ring while it runs (its L+R chain is one composite filter): the ring
+    is made at the launch's end from the discriminator history, and met again at the next launch's start (lr_head_fix) - five one-block
+    launches here, so the second to fifth start from a ring the launch before made."""
+    nb = 5
+    _, _, s = oracle_run(CONFIGS[name], lcg40[: nb * BL])
+    _, _, b = gpu_run(R, CONFIGS[name], lcg40[: nb * BL], nb, fast_math, launches=nb)
+    a, g = s.get_state(), b.get_state(0)
+    assert a.acc == g.acc
+    for f, tol in (("br", 2e-6), ("bm", 4e-6), ("bs", 1e-4)):   # (bs: noise has no pilot - the regenerated carrier is ill-conditioned, the redo threshold is what bounds it)
+        d = np.abs(np.array(list(getattr(a, f))[:90], dtype=np.float64) - np.array(list(getattr(g, f))[:90], dtype=np.float64)).max()
+        assert d <= tol, (f, d)
 
 
 def test_many_streams_independent(R):

@@ -128,5 +128,8 @@ def test_stage_d_stays_on_the_vector_alu_where_its_error_estimate_is_too_large(R
     for vol in (0.4, 8.0):                                   # 300 k stereo / mono: 0.08 - 0.09 LSB at volume 8
         for name in ("stereo_300k", "mono_300k"):
             b = R.BatchDemod(R.wbfm_config(block_len=BL, math=R.MATH_FAST, volume=vol, **CONFIGS[name]), 1)
-            assert b.math == R.MATH_FAST_MFMA_D, (name, vol, b.math)
+            # stereo at the default volume: the composite L+R filter on top (_MFMA_E); at volume 8 its estimate (0.39: the two end taps that
+            # two of sixteen rows lack) keeps the two-stage form
+            want = R.MATH_FAST_MFMA_E if (name == "stereo_300k" and vol == 0.4) else R.MATH_FAST_MFMA_D
+            assert b.math == want, (name, vol, b.math)
             b.close()

@@ -1,7 +1,9 @@
 // What an instruction costs at the package power cap: every SIMD of the chip streams ONE instruction class (W waves per SIMD), the host counts
 // wave-instructions per second; tools/power_price.sh samples rocm-smi beside it.  energy per wave-instruction <= package power / rate (an upper
 // bound: the package draws ~280 W doing nothing).   hipcc --offload-arch=gfx950 -O2 -o power_price power_price.hip ; ./power_price <kind> [waves per SIMD] [seconds]
-//   kinds: mfma (v_mfma_i32_16x16x64_i8), fma (v_fma_f32), pkfma (v_pk_fma_f32), mix (1 MFMA : 5 v_fma_f32 : the stereo kernel's ratio), nop (s_nop)
+//   kinds: mfma (v_mfma_i32_16x16x64_i8), fma (v_fma_f32), pkfma (v_pk_fma_f32), mix (1 MFMA : 5 v_fma_f32 : the stereo kernel's ratio), nop (s_nop),
+//          lds128 / lds64 / lds32 (ds_read_b128 / _b64 / _b32 of the lane's own aligned word: what an MFMA operand read costs), ldsw128 (ds_write_b128),
+//          perm (v_perm_b32), cvt (v_cvt_rpi_i32_f32), dpp (v_mov_b32 row_shr:1)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -18,9 +20,23 @@ __global__ __launch_bounds__(256) void k(int iters, float *sink) {
   f2 p[4];
   for (int i = 0; i < 8; i++) f[i] = (float)(threadIdx.x + i) * 1e-3f;
   for (int i = 0; i < 4; i++) p[i] = f2{f[i], f[i + 4]};
+  __shared__ i4 lbuf[256 * 4];
+  for (int i = threadIdx.x; i < 256 * 4; i += 256) lbuf[i] = i4{i, i + 1, i + 2, i + 3};
+  __syncthreads();
+  typedef __attribute__((address_space(3))) i4 lds_i4;
+  lds_i4 *lp = (lds_i4 *)&lbuf[threadIdx.x];
+  i4 ld[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  int pi[4] = {(int)threadIdx.x, 77, 99, 1234567};
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
+      if constexpr (KIND == 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[u & 3]) : "v"(lp), "n"((u & 3) * 4096));
+      if constexpr (KIND == 6) { long long t; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(lp), "n"((u & 3) * 4096)); ld[u & 3].x ^= (int)t; }
+      if constexpr (KIND == 7) { int t; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t) : "v"(lp), "n"((u & 3) * 4096)); ld[u & 3].x ^= t; }
+      if constexpr (KIND == 8) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lp), "v"(ld[u & 3]), "n"((u & 3) * 4096) : "memory");
+      if constexpr (KIND == 9) pi[u & 3] = __builtin_amdgcn_perm(pi[u & 3], pi[(u + 1) & 3], 0x05010602u);
+      if constexpr (KIND == 10) asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(pi[u & 3]) : "v"(f[u & 7]));
+      if constexpr (KIND == 11) pi[u & 3] = __builtin_amdgcn_update_dpp(0, pi[(u + 1) & 3], 0x111, 0xf, 0xf, true);
       if constexpr (KIND == 0) acc[u & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[u & 3], 0, 0, 0);
       if constexpr (KIND == 1) f[u & 7] = __builtin_fmaf(f[u & 7], 1.0001f, 0.5f);
       if constexpr (KIND == 2) p[u & 3] = __builtin_elementwise_fma(p[u & 3], f2{1.0001f, 0.9999f}, f2{0.5f, 0.25f});
@@ -31,7 +47,9 @@ __global__ __launch_bounds__(256) void k(int iters, float *sink) {
       if constexpr (KIND == 4) asm volatile("s_nop 0");
     }
   }
+  if constexpr (KIND >= 5 && KIND <= 8) asm volatile("s_waitcnt lgkmcnt(0)");
   float s = 0.f;
+  for (int i = 0; i < 4; i++) s += (float)(ld[i].x + ld[i].y + ld[i].z + ld[i].w + pi[i]);
   for (int i = 0; i < 8; i++) s += f[i];
   for (int i = 0; i < 4; i++) s += p[i].x + p[i].y + (float)(acc[i].x + acc[i].y + acc[i].z + acc[i].w);
   if (s == 12345.678f) sink[0] = s;
@@ -52,6 +70,13 @@ int main(int argc, char **argv) {
     else if (!strcmp(kind, "fma")) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, iters, sink);
     else if (!strcmp(kind, "pkfma")) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, iters, sink);
     else if (!strcmp(kind, "mix")) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "lds128")) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "lds64")) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "lds32")) hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "ldsw128")) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "perm")) hipLaunchKernelGGL(k<9>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "cvt")) hipLaunchKernelGGL(k<10>, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    else if (!strcmp(kind, "dpp")) hipLaunchKernelGGL(k<11>, dim3(blocks), dim3(256), 0, 0, iters, sink);
     else hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, iters, sink);
   };
   for (int i = 0; i < 3; i++) launch();
