@@ -62,6 +62,8 @@ def parse():
                          "`noise_input` / `quiet_input` (the same workload on uniform random bytes / on bytes in {127, 128} with mute "
                          "fills, parity-checked) and `modes` (mono and NFM on the same device)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0)
+    ap.add_argument("--only-sustained", action="store_true",
+                    help="of the extra legs run `sustained` (with its hwmon power / clock samples) alone: tools/energy_ablate.sh")
     ap.add_argument("--e2e-streams", type=int, default=64)
     ap.add_argument("--e2e-jobs", type=int, default=20)
     ap.add_argument("--force-dist", action="store_true",
@@ -496,6 +498,61 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+class PowerWatch:
+    """Package power and shader clock of ONE device, read from its hwmon files (amdgpu: power1_input in microwatts, power1_cap,
+    freq1_input in Hz) by a thread while a leg of the bench runs.  No rocm-smi process, no HIP call; silently absent where the files are
+    (the device is found by its PCI address).  Reported beside `sustained`: the kernel is bound by the package power cap, not by a unit
+    of the CU, and this is the driver-run line's own evidence of it."""
+
+    def __init__(self, props, period=0.05):
+        import glob
+        self.dir, self.period, self.rows, self.th = None, period, [], None
+        try:
+            want = "%04x:%02x:%02x." % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        except Exception:
+            return
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            if want in os.path.realpath(d) + ".":
+                h = glob.glob(d + "/hwmon/hwmon*/power1_input")
+                if h:
+                    self.dir = os.path.dirname(h[0])
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def start(self):
+        if not self.dir:
+            return
+        import threading
+        self.stop_flag = threading.Event()
+
+        def run():
+            while not self.stop_flag.is_set():
+                self.rows.append((self._read(self.dir + "/power1_input"), self._read(self.dir + "/freq1_input")))
+                self.stop_flag.wait(self.period)
+        self.th = threading.Thread(target=run, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        if not self.th:
+            return None
+        self.stop_flag.set()
+        self.th.join()
+        rows = self.rows[len(self.rows) // 4:]          # the first quarter: the sensor's averaging window still holds the time before the leg
+        pw = [r[0] * 1e-6 for r in rows if r[0]]
+        fq = [r[1] * 1e-6 for r in rows if r[1]]
+        if not pw:
+            return None
+        cap = self._read(self.dir + "/power1_cap")
+        return {"package_w_mean": round(sum(pw) / len(pw), 1), "package_w_max": round(max(pw), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
+                "sclk_mhz_mean": round(sum(fq) / len(fq), 1) if fq else None, "samples": len(pw), "source": "hwmon power1_input / freq1_input, 50 ms period"}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -647,12 +704,18 @@ def main():
 
     if not args.no_extra and not args.dry_run:
         n_sus = max(args.steps, int(math.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
+        watch = PowerWatch(torch.cuda.get_device_properties(dev))   # package power and shader clock (hwmon) while the leg runs
+        watch.start()
         wall, k_ms = timed_launches(iq, n_sus)
+        power = watch.stop()
         sustained = {"launches": n_sus, "seconds": round(wall, 3), "ms_per_step": round(wall / n_sus * 1e3, 4),
                      "kernel_ms": round(k_ms, 4), "value": round(samples_per_step * n_sus / wall / 1e6, 1),
                      "frac": round(algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "back-to-back launches of the timed workload right after the timed region; whole-rank rate"}
-        if args.data != "noise":
+        if power:
+            # what bounds this kernel: the package sits at its power cap and the shader clock is what the cap leaves
+            sustained["power"] = power
+        if args.data != "noise" and not args.only_sustained:
             # uniform random bytes = a pilot-less, full-band input: the ill-conditioned-sample redo paths of the +-1 LSB
             # kernels (branch cut / origin of the discriminator, carrier regeneration without a pilot) run here
             gn = torch.Generator(device=dev)
@@ -670,7 +733,7 @@ def main():
             torch.cuda.synchronize(dev)
             quiet_leg = input_leg(iq_n, "synthetic quiet input: bytes in {127, 128}, 4096-byte mute fills of 127, one stream in eight constant 127")
             del iq_n
-        if world == 1 and args.mode == "stereo" and args.math == "fast":
+        if world == 1 and args.mode == "stereo" and args.math == "fast" and not args.only_sustained:
             # the other modes of the path on this device, same shape of run (BASELINE.json configs[0] / [4] at 256 streams): never `value`
             modes_leg = {}
             for mname, mkw, rate in (("mono", dict(rate_in=300000, rate_out2=48000, mode=1), 2.4e6),
@@ -801,7 +864,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg_kw, args.cpu_seconds, iq)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
-        if not args.no_extra and world == 1:
+        if not args.no_extra and not args.only_sustained and world == 1:
             out["single_stream"] = single_stream_leg(R, cfg_kw, math_code)
         if not args.no_e2e and world == 1:
             out["e2e_h2d"] = e2e_h2d(args.mode, min(args.e2e_streams, S), B, args.e2e_jobs, math_code, cfg_kw)

@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/${SOAK_TAG:-r06s}; mkdir -p $O
 for s in $(seq ${SOAK_SEED0:-21} ${SOAK_SEED1:-60}); do timeout 600 python tools/fuzz_parity.py 400 $s 2>&1 | grep -v amdgpu | tail -1; done > $O/fuzz_soak.txt
 FUZZ_VOLUMES=1 timeout 600 python tools/fuzz_parity.py 400 1 2>&1 | grep -v amdgpu | tail -1 >> $O/fuzz_soak.txt
-for fam in 2 3 4 5; do for kind in 0 1; do timeout 900 python tools/diag/coburst.py $fam 400 2 $kind 2>&1 | tail -1; done; done > $O/coburst_soak.txt
-for fam in 2 3 5; do timeout 900 python tools/diag/coburst.py $fam 400 1 0 2>&1 | tail -1; done >> $O/coburst_soak.txt
-timeout 900 python tools/diag/determinism.py 5 2000 2 2>&1 | tail -2 > $O/determinism.txt
+for fam in ${SOAK_FAMS:-2 3 4 5 6}; do for kind in 0 1; do timeout 900 python tools/diag/coburst.py $fam 400 2 $kind 2>&1 | tail -1; done; done > $O/coburst_soak.txt
+for fam in ${SOAK_FAMS_MONO:-2 3 5}; do timeout 900 python tools/diag/coburst.py $fam 400 1 0 2>&1 | tail -1; done >> $O/coburst_soak.txt
+timeout 900 python tools/diag/determinism.py 6 2000 2 2>&1 | tail -2 > $O/determinism.txt
+timeout 900 python tools/diag/determinism.py 5 1000 2 2>&1 | tail -2 >> $O/determinism.txt
 timeout 900 python tools/diag/determinism.py 4 1000 2 2>&1 | tail -2 >> $O/determinism.txt
 timeout 900 python tools/diag/determinism.py 3 1000 1 2>&1 | tail -2 >> $O/determinism.txt
 timeout 900 python tools/diag/determinism.py 5 2000 1 2>&1 | tail -2 >> $O/determinism.txt
