@@ -128,6 +128,13 @@ def test_bench_line_contract(R):
     assert set(d["modes"]) == {"mono", "nfm"}
     for m in d["modes"].values():
         assert m["parity"]["max_abs_lsb"] <= 1 and 0 < m["frac"] < 1 and m["kernel_ms"] > 0
+    # the stereo default is the family with the composite L+R filter, and the sustained leg carries the package power / shader clock it ran at
+    # where the device's hwmon files exist (they do on the MI355X boxes of the pool)
+    assert d["config"]["kernel_family"] == "fast-mfma-e"
+    pw = d["sustained"].get("power")
+    import glob
+    if glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        assert pw and 100 < pw["package_w_mean"] <= pw["package_w_max"] <= 1.05 * pw["cap_w"] and pw["sclk_mhz_mean"] > 300, pw
 
 
 def test_rccl_counter_gather_runs_on_one_gpu(R):
