@@ -134,7 +134,7 @@ static int check_config(const fmd_config *c) {
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
   if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_E)
-    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_C");
+    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA, _FAST_MFMA_C, _FAST_MFMA_D or _FAST_MFMA_E");
   /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
    * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
   if (c->math != FMD_MATH_EXACT && c->deemph && !(c->deemph_lambda > 0.f && c->deemph_lambda < 1.f))
@@ -567,9 +567,9 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
    * fmd_config.math; FMD_MFMA is read by tuning builds only) */
   if (b->cfg.math == FMD_MATH_FAST) {
     const char *e_m = tuning_env("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 4;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3 (default):
-                                                     stages A, C and D (90-tap stereo with whole tiles; what a configuration cannot
-                                                     run resolves downwards, see below) */
+    const int sel = e_m ? atoi(e_m) : 4;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3: stages A, C
+                                                     and D, 4 (default): ... with the stereo L+R chain as one composite filter (90-tap
+                                                     stereo with whole tiles; what a configuration cannot run resolves downwards, see below) */
     b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : sel == 3 ? FMD_MATH_FAST_MFMA_D : FMD_MATH_FAST_MFMA_E;
   }
   if (taps) b->taps = *taps;
