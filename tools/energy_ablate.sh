@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: what a stage costs in ENERGY.  Builds with stages compiled out (tools/ablate.sh <mask>: 1 A, 2 B, 4 C, 8 D, 16 F -> .ablate/lib_ab<mask>.so)
 # and the shipped library, each through bench.py's `sustained` leg (3 s of back-to-back launches) with the package power and shader clock
-# sampled from hwmon beside it (bench.py: PowerWatch): energy per launch = mean power x kernel time.   tools/energy_ablate.sh <tag> [mode] [masks...]
+# sampled from hwmon beside it (bench.py: PowerWatch): energy per launch (joules) = mean power x kernel time.   tools/energy_ablate.sh <tag> [mode] [masks...]
 TAG=$1; MODE=${2:-stereo}; shift 2
 MASKS=${*:-full 1 2 4 8 16 12 30 31}
 cd $GRAFT_REPO_ROOT; O=gpurun_out/$TAG; mkdir -p $O
@@ -12,6 +12,6 @@ for round in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['sustained']; p = s.get('power') or {}
 w = p.get('package_w_mean'); t = s['kernel_ms']
-print('ablate=$m round=$round mode=$MODE kernel_ms', t, 'package_w', w, 'max', p.get('package_w_max'), 'sclk_mhz', p.get('sclk_mhz_mean'), 'mJ_per_launch', round(w * t * 1e-3, 4) if w else None)"
+print('ablate=$m round=$round mode=$MODE kernel_ms', t, 'package_w', w, 'max', p.get('package_w_max'), 'sclk_mhz', p.get('sclk_mhz_mean'), 'J_per_launch', round(w * t * 1e-3, 4) if w else None)"
   done
 done | tee $O/energy_ablate_$MODE.txt
