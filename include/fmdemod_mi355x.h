@@ -192,6 +192,13 @@ void fmd_demod_release(struct demod_state *d);
                                   default of FMD_MATH_FAST there since round 5; 128-tap mono and everything else run what
                                   FMD_MATH_FAST_MFMA_D runs */
 
+#define FMD_MATH_FAST_MFMA_F 7 /* ... with the stereo second stage (the composite L+R filter and fm over (L-R) x carrier) evaluated at the
+                                  resampler's emit instants only, as the reference does (src/rtl_fm_player.c:570-598): a decimating banded
+                                  product - rows = sixteen consecutive frames, columns = (group of sixteen frames, sample limb) - 32 matrix
+                                  instructions per tile where the full-rate form took 60.  Needs 16 rate_out a multiple of 4 rate_out2 with
+                                  4 <= rate_out / rate_out2 <= 6.25 (300 k, 240 k, 192 k -> 48 k); the default of FMD_MATH_FAST there
+                                  since round 6; everything else runs what FMD_MATH_FAST_MFMA_E runs */
+
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
   int32_t rate_out;       /* demod_state.rate_out  (resampler "fast")          */
@@ -204,7 +211,7 @@ typedef struct fmd_config {
   float volume;           /* demod_state.volume                                */
   int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
                           /* multiple of 16, >= 64                             */
-  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D / _MFMA_E) */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D / _MFMA_E / _MFMA_F) */
 } fmd_config;
 
 /* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /

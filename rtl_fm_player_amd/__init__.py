@@ -14,6 +14,7 @@ from .capi import (  # noqa: F401
     MATH_FAST_MFMA_C,
     MATH_FAST_MFMA_D,
     MATH_FAST_MFMA_E,
+    MATH_FAST_MFMA_F,
     MATH_FAST_VALU,
     BatchDemod,
     DemodState,

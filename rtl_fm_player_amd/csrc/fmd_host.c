@@ -133,8 +133,8 @@ static int check_config(const fmd_config *c) {
   if (c->mode < 0 || c->mode > 2) return fail(FMD_E_ARG, "lpr.mode must be 0, 1 or 2");
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
-  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_E)
-    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA, _FAST_MFMA_C, _FAST_MFMA_D or _FAST_MFMA_E");
+  if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_F)
+    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA, _FAST_MFMA_C, _FAST_MFMA_D, _FAST_MFMA_E or _FAST_MFMA_F");
   /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
    * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
   if (c->math != FMD_MATH_EXACT && c->deemph && !(c->deemph_lambda > 0.f && c->deemph_lambda < 1.f))
@@ -353,7 +353,7 @@ static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
  * (accumulators read as floats) and the same error estimate as stage D's (one quantisation of the samples instead of two).  The kernel's
  * window holds 192 samples for 16 shifted rows: taps 177 and 178 (fm[0]^2 and 2 fm[0] fm[1]) are missing in row 0, tap 178 in row 1 -
  * their weight is part of the estimate. */
-static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
+static int build_lr_composite(const fmd_taps *t, fmdk_params *k, int short_window) {
   if (k->size != 90) return -1;
   double g[179];
   for (int u = 0; u < 179; u++) {
@@ -384,7 +384,7 @@ static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
   const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * 179.0) * 74.0 * 74.0;
   const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
   const double taps = sqrt(179.0) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
-  const double ends = (fabs(g[177]) + fabs(g[178])) * 1.8;
+  const double ends = short_window ? (fabs(g[177]) + fabs(g[178])) * 1.8 : 0.0;   /* (_MFMA_F's window holds every tap of every row) */
   if (fabs((double)k->coef) * (sqrt(dropped * dropped + samples * samples + taps * taps) + ends) > FMD_STAGE_D_MAX_LSB) return -1;
   k->g_qf = qf;
   k->g_scale = (float)ldexp(1.0, 12 - qf);
@@ -567,16 +567,17 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
    * fmd_config.math; FMD_MFMA is read by tuning builds only) */
   if (b->cfg.math == FMD_MATH_FAST) {
     const char *e_m = tuning_env("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 4;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3: stages A, C
+    const int sel = e_m ? atoi(e_m) : 5;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3: stages A, C
                                                      and D, 4 (default): ... with the stereo L+R chain as one composite filter (90-tap
                                                      stereo with whole tiles; what a configuration cannot run resolves downwards, see below) */
-    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : sel == 3 ? FMD_MATH_FAST_MFMA_D : FMD_MATH_FAST_MFMA_E;
+    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : sel == 3 ? FMD_MATH_FAST_MFMA_D : sel == 4 ? FMD_MATH_FAST_MFMA_E : FMD_MATH_FAST_MFMA_F;
   }
   if (taps) b->taps = *taps;
   else if ((rc = fmd_design_taps(cfg, &b->taps))) return rc;
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
-  const int want_e = b->cfg.math == FMD_MATH_FAST_MFMA_E;
+  const int want_f = b->cfg.math == FMD_MATH_FAST_MFMA_F;   /* _F is _E with the second stage at the emit instants only: _E's conditions first */
+  const int want_e = want_f || b->cfg.math == FMD_MATH_FAST_MFMA_E;
   if (want_e) b->cfg.math = FMD_MATH_FAST_MFMA_D;   /* _E is _D with the L+R chain as one filter: the same conditions first */
   if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
     /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone.
@@ -588,8 +589,19 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
     } else if (!(b->cfg.mode == 2 && whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 &&
                  stage_d_on_matrix_pipe(&b->taps, &b->kp)))
       b->cfg.math = FMD_MATH_FAST_MFMA_C;
-    else if (want_e && b->cfg.mode == 2 && build_lr_composite(&b->taps, &b->kp) == 0)
-      b->cfg.math = FMD_MATH_FAST_MFMA_E;
+    else if (want_e && b->cfg.mode == 2) {
+      /* the decimating second stage (resample_tile_dec): sixteen frames are a whole number P of samples, P a multiple of four (the groups' sample
+       * windows start P c - K0 bytes into the limb arrays: dword reads) and at most 100 (window K0 + P: five K slices for the composite filter,
+       * three for fm); P >= 64 is rate_out >= 4 rate_out2, which _MFMA_D has checked */
+      const long long p16 = 16LL * b->kp.fast;
+      const int dec = want_f && p16 % b->kp.slow == 0 && (p16 / b->kp.slow) % 4 == 0 && p16 / b->kp.slow >= 64 && p16 / b->kp.slow <= 100;
+      if (dec && build_lr_composite(&b->taps, &b->kp, 0) == 0) {
+        b->kp.dec_p = (int32_t)(p16 / b->kp.slow);
+        b->cfg.math = FMD_MATH_FAST_MFMA_F;
+      } else if (build_lr_composite(&b->taps, &b->kp, 1) == 0) {
+        b->cfg.math = FMD_MATH_FAST_MFMA_E;
+      }
+    }
   }
   if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {
     /* stage C on the matrix pipe: 90-tap stereo with whole tiles (block_len a multiple of 8192 bytes); anything else runs the
@@ -599,7 +611,7 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
       b->cfg.math = FMD_MATH_FAST_MFMA;
   }
   if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D ||
-      b->cfg.math == FMD_MATH_FAST_MFMA_E) {
+      b->cfg.math == FMD_MATH_FAST_MFMA_E || b->cfg.math == FMD_MATH_FAST_MFMA_F) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
       if (cfg->math != FMD_MATH_FAST) { return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }

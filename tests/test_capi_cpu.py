@@ -74,11 +74,11 @@ def test_design_taps_equals_oracle():
     dict(block_len=100), dict(block_len=32), dict(size=91), dict(size=300), dict(mode=3),
     dict(rate_out2=200000),          # stereo beyond rate_out / 3
     dict(rate_out2=0, mode=2),
-    dict(math=7), dict(math=-1),
+    dict(math=8), dict(math=-1),
     # the +-1 LSB kernels evaluate the de-emphasis with powers of lambda: they need a contraction
     dict(math=R.MATH_FAST, deemph_lambda=1.0), dict(math=R.MATH_FAST_VALU, deemph_lambda=0.0),
     dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5), dict(math=R.MATH_FAST_MFMA_D, deemph_lambda=1.0),
-    dict(math=R.MATH_FAST_MFMA_E, deemph_lambda=1.0),
+    dict(math=R.MATH_FAST_MFMA_E, deemph_lambda=1.0), dict(math=R.MATH_FAST_MFMA_F, deemph_lambda=1.0),
 ])
 def test_bad_configs_are_rejected(bad):
     bad = dict(bad)
@@ -94,7 +94,7 @@ def test_bad_configs_are_rejected(bad):
 @pytest.mark.parametrize("ok", [
     dict(math=R.MATH_EXACT, deemph_lambda=1.0), dict(math=R.MATH_EXACT, deemph_lambda=0.0),   # the exact kernels take any lambda
     dict(math=R.MATH_FAST, deemph=False, deemph_lambda=1.0),                                  # ... and it is not read with de-emphasis off
-    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D), dict(math=R.MATH_FAST_MFMA_E),
+    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D), dict(math=R.MATH_FAST_MFMA_E), dict(math=R.MATH_FAST_MFMA_F),
 ])
 def test_good_configs_are_accepted(ok):
     lam = ok.pop("deemph_lambda", None)
@@ -107,10 +107,15 @@ def test_good_configs_are_accepted(ok):
 
 @pytest.mark.parametrize("kw,want", [
     # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2: stages A, C, D on the matrix pipe, the L+R chain as one composite filter ...
-    (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_E"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_E"),
-    (dict(rate_in=240000, rate_out2=48000, mode=2, volume=3.0), "MFMA_E"),
-    # ... while the composite's error estimate (its two end taps are missing in two of sixteen rows) stays below 0.15 LSB: not at volume 8
-    (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_D"),
+    # ... and, where sixteen frames are a whole number P of samples (P a multiple of four in 64 .. 100), the second stage at the emit instants only
+    (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_F"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_F"),
+    (dict(rate_in=240000, rate_out2=48000, mode=2, volume=3.0), "MFMA_F"),
+    # (P = 16 x 220 / 48 is no integer; 16 x 330 / 48 = 110 needs a sixth K slice: the full-rate second stage)
+    (dict(rate_in=220000, rate_out2=48000, mode=2), "MFMA_E"), (dict(rate_in=330000, rate_out2=48000, mode=2), "MFMA_E"),
+    # ... while the composite's error estimate stays below 0.15 LSB: the full-rate form's window lacks the two end taps in two of sixteen rows
+    # (0.39 at volume 8 -> the two-stage form), the decimating form's holds them all (volume 8 passes, 12 does not)
+    (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_F"), (dict(rate_in=300000, rate_out2=48000, mode=2, volume=12.0), "MFMA_D"),
+    (dict(rate_in=220000, rate_out2=48000, mode=2, volume=8.0), "MFMA_D"),
     # rate_out < 4 rate_out2: the selection of stage D does not apply - stage C alone
     (dict(rate_in=171000, rate_out2=44100, mode=2), "MFMA_C"),
     # other filter sizes, ragged tiles: stage A only
@@ -128,11 +133,14 @@ def test_good_configs_are_accepted(ok):
 def test_family_resolution_needs_no_device(kw, want):
     """What FMD_MATH_FAST (and the named family) resolves to is decided on the host before the device is touched (fmd_config_family):
     the rules of DESIGN.md section 1 / 2a, checked here without a GPU."""
-    code = {"MFMA_E": R.MATH_FAST_MFMA_E, "MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA, "VALU": R.MATH_FAST_VALU}[want]
-    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_E):
+    code = {"MFMA_F": R.MATH_FAST_MFMA_F, "MFMA_E": R.MATH_FAST_MFMA_E, "MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA,
+            "VALU": R.MATH_FAST_VALU}[want]
+    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F):
         assert R.config_family(R.wbfm_config(math=m, **kw)) == code, (kw, m)
-    # the family of round 5's first half, named: what it was
-    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_D, **kw)) == (R.MATH_FAST_MFMA_D if want == "MFMA_E" else code), kw
+    # the families of round 5, named: what they were
+    short_window_fails = kw.get("volume", 0.4) >= 8.0       # (the full-rate composite filter's estimate with its two missing end taps)
+    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_E, **kw)) == ((R.MATH_FAST_MFMA_D if short_window_fails else R.MATH_FAST_MFMA_E) if want == "MFMA_F" else code), kw
+    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_D, **kw)) == (R.MATH_FAST_MFMA_D if want in ("MFMA_E", "MFMA_F") else code), kw
     assert R.config_family(R.wbfm_config(math=R.MATH_EXACT, **kw)) == R.MATH_EXACT
     assert R.config_family(R.wbfm_config(math=R.MATH_FAST_VALU, **kw)) == R.MATH_FAST_VALU
 

@@ -14,7 +14,7 @@ from oracle import OracleStream
 BL, NB, NS = 262144, 4, 16
 dev = torch.device("cuda:0")
 iq = bench.synth_fm_iq(torch, dev, NS, NB * BL // 2, 2400000.0, True, 4242).cpu().numpy().reshape(NS, NB, BL)
-FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E}
+FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E, "mfma_f": R.MATH_FAST_MFMA_F}
 worst_all = 0
 for rate_in in (300000, 240000):
     for vol in (0.4, 1.0, 2.0, 2.5, 3.0, 3.5, 5.0, 8.0):
