@@ -778,7 +778,7 @@ def main():
                 mbytes = S * B * BLOCK_LEN + int(mlens.sum().item()) * 2
                 modes_leg[mname] = {
                     "workload": "%d concurrent %s streams per GPU x %d blocks" % (S, "2.4 Msps mono WBFM" if mname == "mono" else "200 ksps narrow-FM mono", B),
-                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_D: "fast-mfma-d"}.get(mb.math, str(mb.math)),
+                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_D: "fast-mfma-d", R.MATH_FAST_MFMA_F: "fast-mfma-f"}.get(mb.math, str(mb.math)),
                     "steps": args.steps, "kernel_ms": round(mk, 4), "ms_per_step": round(mwall / args.steps * 1e3, 4),
                     "value": round(samples_per_step * args.steps / mwall / 1e6, 1), "unit": "Msamples/s",
                     "algorithmic_bytes_per_launch": mbytes, "achieved_gbs": round(mbytes / (mk * 1e-3) / 1e9, 1),

@@ -586,6 +586,16 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
     if (b->cfg.mode == 1) {
       if (!(whole && build_ci_scales_mono(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp)))
         b->cfg.math = FMD_MATH_FAST_MFMA;
+      else if (want_f) {
+        /* the decimating form (resample_mono_dec): sixteen frames are P samples, P a multiple of four in 32 .. 128 (window 128 + P <= 256: four K slices);
+         * below 64 a tile holds more than eight groups of sixteen frames: a column per group */
+        const long long p16 = 16LL * b->kp.fast;
+        if (p16 % b->kp.slow == 0 && (p16 / b->kp.slow) % 4 == 0 && p16 / b->kp.slow >= 32 && p16 / b->kp.slow <= 128) {
+          b->kp.dec_p = (int32_t)(p16 / b->kp.slow);
+          b->kp.dec_wide = b->kp.dec_p < 64;
+          b->cfg.math = FMD_MATH_FAST_MFMA_F;
+        }
+      }
     } else if (!(b->cfg.mode == 2 && whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 &&
                  stage_d_on_matrix_pipe(&b->taps, &b->kp)))
       b->cfg.math = FMD_MATH_FAST_MFMA_C;

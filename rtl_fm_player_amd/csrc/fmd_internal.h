@@ -87,6 +87,7 @@ typedef struct fmdk_params {
   int32_t g_qf;
   float g_scale, g_unit;
   int32_t dec_p;                 /* FMD_MATH_FAST_MFMA_F: 16 rate_out / rate_out2 = samples per sixteen frames (a multiple of four in 64 .. 100), 0: the family does not apply (resample_tile_dec) */
+  int32_t dec_wide;              /* ... mono: more than eight groups of sixteen frames per tile (rate_out < 4 rate_out2): a column per group (resample_mono_dec) */
   int32_t pilot_pairs8;          /* matrix-pipe stage C: the pilot filter's class-3 limb pairs too (volume >= 1: the carrier's accuracy in LSB scales with it) */
   float org_thr, org_thr15;      /* (and 1.5 x it: the lane-level pre-test on max(|cross|, |dot|)) */
 } fmdk_params;

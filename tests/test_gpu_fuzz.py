@@ -128,9 +128,9 @@ def test_bench_line_contract(R):
     assert set(d["modes"]) == {"mono", "nfm"}
     for m in d["modes"].values():
         assert m["parity"]["max_abs_lsb"] <= 1 and 0 < m["frac"] < 1 and m["kernel_ms"] > 0
-    # the stereo default is the family with the composite L+R filter, and the sustained leg carries the package power / shader clock it ran at
+    # the stereo default is the family with the composite L+R filter and the second stage at the emit instants only, and the sustained leg carries the package power / shader clock it ran at
     # where the device's hwmon files exist (they do on the MI355X boxes of the pool)
-    assert d["config"]["kernel_family"] == "fast-mfma-e"
+    assert d["config"]["kernel_family"] == "fast-mfma-f"
     pw = d["sustained"].get("power")
     import glob
     if glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):

@@ -3,7 +3,12 @@ sys.path.insert(0, '.')
 import rtl_fm_player_amd as R
 from oracle import OracleStream, lcg_bytes
 bl, nb = 262144, 6
-for kw in (dict(rate_in=300000, rate_out2=48000, mode=2), dict(rate_in=240000, rate_out2=48000, mode=2), dict(rate_in=192000, rate_out2=48000, mode=2)):
+import sys as _s
+CASES = (dict(rate_in=300000, rate_out2=48000, mode=2), dict(rate_in=240000, rate_out2=48000, mode=2), dict(rate_in=192000, rate_out2=48000, mode=2))
+if len(_s.argv) > 1 and _s.argv[1] == "mono":
+    CASES = (dict(rate_in=300000, rate_out2=48000, mode=1), dict(rate_in=240000, rate_out2=48000, mode=1), dict(rate_in=192000, rate_out2=48000, mode=1),
+             dict(rate_in=25000, rate_out2=12500, mode=1), dict(rate_in=96000, rate_out2=32000, mode=1), dict(rate_in=384000, rate_out2=48000, mode=1))
+for kw in CASES:
     iq, _ = lcg_bytes(nb * bl, 12345)
     want, wl = OracleStream(**kw).run(iq, bl)
     outs = {}
