@@ -743,38 +743,44 @@ def main():
                 mpcm = torch.zeros((S, B, mb.pcm_stride), dtype=torch.int16, device=dev)
                 mlens = torch.zeros((S, B), dtype=torch.int32, device=dev)
                 torch.cuda.synchronize(dev)                 # the launches go to `stream`, torch made these on its own
-                mpar = None
-                if not args.no_check:
-                    from concurrent.futures import ThreadPoolExecutor
-                    from oracle import OracleStream
-                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+
+                def mode_measure(t_iq):
+                    """parity of EVERY stream against the oracle, the timed workload's preheat, then --steps timed launches of this mode's batch"""
+                    par = None
+                    if not args.no_check:
+                        from concurrent.futures import ThreadPoolExecutor
+                        from oracle import OracleStream
+                        mb.reset()
+                        mb.run_device(t_iq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+                        torch.cuda.synchronize(dev)
+                        h_iq, h_pcm, h_lens = t_iq.cpu().numpy(), mpcm.cpu().numpy(), mlens.cpu().numpy()
+
+                        def mcheck(si):
+                            want, wl = OracleStream(**mkw).run(h_iq[si].reshape(-1), BLOCK_LEN)
+                            if not np.array_equal(h_lens[si], wl):
+                                return 1 << 20
+                            got = np.concatenate([h_pcm[si, b, :wl[b]] for b in range(B)])
+                            return int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()) if got.size else 0
+
+                        with ThreadPoolExecutor(max(1, min(usable_cores(), 32))) as ex:
+                            worst = max(ex.map(mcheck, range(S)))
+                        assert worst <= 1, "%s: PCM differs from the CPU oracle by %d LSB" % (mname, worst)
+                        par = {"max_abs_lsb": worst, "tolerance_lsb": 1, "streams_checked": S}
+                        mb.reset()
+                    mb.set_timing(False)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    for _ in range(max(args.preheat, args.warmup, 2)):
+                        mb.run_device(t_iq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
                     torch.cuda.synchronize(dev)
-                    h_iq, h_pcm, h_lens = miq.cpu().numpy(), mpcm.cpu().numpy(), mlens.cpu().numpy()
+                    w0 = time.perf_counter()
+                    e0.record(stream)
+                    for _ in range(args.steps):
+                        mb.run_device(t_iq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
+                    e1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    return par, time.perf_counter() - w0, e0.elapsed_time(e1) / args.steps
 
-                    def mcheck(si):
-                        want, wl = OracleStream(**mkw).run(h_iq[si].reshape(-1), BLOCK_LEN)
-                        if not np.array_equal(h_lens[si], wl):
-                            return 1 << 20
-                        got = np.concatenate([h_pcm[si, b, :wl[b]] for b in range(B)])
-                        return int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()) if got.size else 0
-
-                    with ThreadPoolExecutor(max(1, min(usable_cores(), 32))) as ex:
-                        worst = max(ex.map(mcheck, range(S)))
-                    assert worst <= 1, "%s: PCM differs from the CPU oracle by %d LSB" % (mname, worst)
-                    mpar = {"max_abs_lsb": worst, "tolerance_lsb": 1, "streams_checked": S}
-                    mb.reset()
-                mb.set_timing(False)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for _ in range(max(args.preheat, args.warmup, 2)):
-                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
-                torch.cuda.synchronize(dev)
-                w0 = time.perf_counter()
-                e0.record(stream)
-                for _ in range(args.steps):
-                    mb.run_device(miq, B, mpcm, mlens, hip_stream=stream.cuda_stream)
-                e1.record(stream)
-                torch.cuda.synchronize(dev)
-                mwall, mk = time.perf_counter() - w0, e0.elapsed_time(e1) / args.steps
+                mpar, mwall, mk = mode_measure(miq)
                 mbytes = S * B * BLOCK_LEN + int(mlens.sum().item()) * 2
                 modes_leg[mname] = {
                     "workload": "%d concurrent %s streams per GPU x %d blocks" % (S, "2.4 Msps mono WBFM" if mname == "mono" else "200 ksps narrow-FM mono", B),
@@ -783,6 +789,19 @@ def main():
                     "value": round(samples_per_step * args.steps / mwall / 1e6, 1), "unit": "Msamples/s",
                     "algorithmic_bytes_per_launch": mbytes, "achieved_gbs": round(mbytes / (mk * 1e-3) / 1e9, 1),
                     "frac": round(mbytes / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "parity": mpar}
+                # ... and this mode on the quiet input of the stereo leg above (the driver's line carries it for every mode)
+                gq = torch.Generator(device=dev)
+                gq.manual_seed(97531 + rank)
+                miq.copy_(torch.randint(127, 129, (S, B, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gq))
+                miq[:, ::4, :4096] = 127
+                miq[::8] = 127
+                torch.cuda.synchronize(dev)
+                qpar, qwall, qk = mode_measure(miq)
+                modes_leg[mname]["quiet_input"] = {
+                    "data": "synthetic quiet input: bytes in {127, 128}, 4096-byte mute fills of 127, one stream in eight constant 127",
+                    "steps": args.steps, "kernel_ms": round(qk, 4), "ms_per_step": round(qwall / args.steps * 1e3, 4),
+                    "value": round(samples_per_step * args.steps / qwall / 1e6, 1), "parity": qpar,
+                    "slowdown_vs_timed_input": round(qk / mk, 3)}
                 del mb, miq, mpcm, mlens
 
     if rank == 0:

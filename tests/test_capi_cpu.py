@@ -121,12 +121,13 @@ def test_good_configs_are_accepted(ok):
     # other filter sizes, ragged tiles: stage A only
     (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=2, block_len=16000), "MFMA"),
     # 128-tap mono / narrow FM: stage D on the matrix pipe at rate_out >= 2 rate_out2 ...
-    (dict(rate_in=300000, rate_out2=48000, mode=1), "MFMA_D"), (dict(rate_in=25000, rate_out2=12500, mode=1), "MFMA_D"),
-    (dict(rate_in=96000, rate_out2=32000, mode=1), "MFMA_D"), (dict(rate_in=48000, rate_out2=32000, mode=1), "MFMA"),
+    # (where sixteen frames are a whole number of samples - a multiple of four in 32 .. 128 - at the emit instants only: _MFMA_F)
+    (dict(rate_in=300000, rate_out2=48000, mode=1), "MFMA_F"), (dict(rate_in=25000, rate_out2=12500, mode=1), "MFMA_F"),
+    (dict(rate_in=96000, rate_out2=32000, mode=1), "MFMA_F"), (dict(rate_in=100000, rate_out2=48000, mode=1), "MFMA_D"), (dict(rate_in=48000, rate_out2=32000, mode=1), "MFMA"),
     (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), "MFMA"),
     # ... while its fixed-point error estimate stays below 0.15 LSB: narrow FM's filter (largest tap 0.58) at volume 3 and 8 does not
-    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=1.0), "MFMA_D"), (dict(rate_in=25000, rate_out2=12500, mode=1, volume=3.0), "MFMA"),
-    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=8.0), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=1, volume=8.0), "MFMA_D"),
+    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=1.0), "MFMA_F"), (dict(rate_in=25000, rate_out2=12500, mode=1, volume=3.0), "MFMA"),
+    (dict(rate_in=25000, rate_out2=12500, mode=1, volume=8.0), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=1, volume=8.0), "MFMA_F"),
     # mode 0 / no resampler
     (dict(rate_in=300000, rate_out2=0, mode=1), "MFMA"),
 ])
@@ -138,7 +139,7 @@ def test_family_resolution_needs_no_device(kw, want):
     for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F):
         assert R.config_family(R.wbfm_config(math=m, **kw)) == code, (kw, m)
     # the families of round 5, named: what they were
-    short_window_fails = kw.get("volume", 0.4) >= 8.0       # (the full-rate composite filter's estimate with its two missing end taps)
+    short_window_fails = kw.get("volume", 0.4) >= 8.0 or kw["mode"] == 1       # (the full-rate composite filter's estimate with its two missing end taps; mono has no composite filter)
     assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_E, **kw)) == ((R.MATH_FAST_MFMA_D if short_window_fails else R.MATH_FAST_MFMA_E) if want == "MFMA_F" else code), kw
     assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_D, **kw)) == (R.MATH_FAST_MFMA_D if want in ("MFMA_E", "MFMA_F") else code), kw
     assert R.config_family(R.wbfm_config(math=R.MATH_EXACT, **kw)) == R.MATH_EXACT

@@ -128,6 +128,8 @@ def test_bench_line_contract(R):
     assert set(d["modes"]) == {"mono", "nfm"}
     for m in d["modes"].values():
         assert m["parity"]["max_abs_lsb"] <= 1 and 0 < m["frac"] < 1 and m["kernel_ms"] > 0
+        q = m["quiet_input"]                      # the quiet-input leg of every mode (round 6)
+        assert q["parity"]["max_abs_lsb"] <= 1 and q["parity"]["streams_checked"] == 32 and q["kernel_ms"] > 0 and q["slowdown_vs_timed_input"] > 0.5
     # the stereo default is the family with the composite L+R filter and the second stage at the emit instants only, and the sustained leg carries the package power / shader clock it ran at
     # where the device's hwmon files exist (they do on the MI355X boxes of the pool)
     assert d["config"]["kernel_family"] == "fast-mfma-f"

@@ -190,12 +190,16 @@ def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R
     # form (_MFMA_F) where sixteen frames are a whole number of samples (a multiple of four up to 100), else the full-rate form (_MFMA_E)
     for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_F), (dict(rate_in=220000, rate_out2=48000, mode=2), R.MATH_FAST_MFMA_E),
                      (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
-                     (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA_D),
-                     (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA_D), (dict(rate_in=96000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA_D), (dict(rate_in=48000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
+                     (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA_F),
+                     (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA_F), (dict(rate_in=96000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA_F),
+                     (dict(rate_in=100000, rate_out2=48000, mode=1), R.MATH_FAST_MFMA_D),     # (16 x 100 / 48 is no integer: the full-rate stage D)
+                     (dict(rate_in=48000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
         for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F, R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_D):   # (_MFMA_E / _MFMA_D named: what they were in round 5)
             b = R.BatchDemod(R.wbfm_config(math=m, **kw), 1)
-            stereo_d = want in (R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_F)
-            expect = R.MATH_FAST_MFMA_D if (m == R.MATH_FAST_MFMA_D and stereo_d) else R.MATH_FAST_MFMA_E if (m == R.MATH_FAST_MFMA_E and stereo_d) else want
+            stereo_d = kw["mode"] == 2 and want in (R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_F)
+            mono_f = kw["mode"] == 1 and want == R.MATH_FAST_MFMA_F          # (mono has no composite filter: _MFMA_E named runs _MFMA_D)
+            expect = (R.MATH_FAST_MFMA_D if (m == R.MATH_FAST_MFMA_D and stereo_d) else R.MATH_FAST_MFMA_E if (m == R.MATH_FAST_MFMA_E and stereo_d) else
+                      R.MATH_FAST_MFMA_D if (mono_f and m in (R.MATH_FAST_MFMA_D, R.MATH_FAST_MFMA_E)) else want)
             assert b.math == expect, (kw, m, b.math)
             b.close()
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, block_len=16 * 1000, **cfg_kw), 1)      # ragged tiles: stage A only
