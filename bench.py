@@ -48,9 +48,9 @@ def parse():
                          "(tools/ramp_check.py: 0.76 ms per launch at first, 0.63 ms from then on)")
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=16, help="reference blocks per stream per step")
-    ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-c", "fast-mfma-d", "fast-mfma-e", "fast-mfma-f"], default="fast",
+    ap.add_argument("--math", choices=["fast", "exact", "fast-valu", "fast-mfma", "fast-mfma-f"], default="fast",
                     help="fast = the +-1 LSB kernel family the library picks for the configuration; "
-                         "fast-valu / fast-mfma / fast-mfma-c / fast-mfma-d / fast-mfma-e / fast-mfma-f name one (A/B runs)")
+                         "fast-valu / fast-mfma / fast-mfma-f name one (A/B runs)")
     ap.add_argument("--mode", choices=["stereo", "mono", "nfm"], default="stereo",
                     help="stereo/mono: 2.4 Msps WBFM (rate_in 300k -> 48k); nfm: 200 ksps (25k -> 12.5k mono)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -592,7 +592,7 @@ def main():
     else:
         cfg_kw = dict(rate_in=300000, rate_out2=48000, mode=2 if stereo else 1)
     math_code = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
-            "fast-mfma-c": R.MATH_FAST_MFMA_C, "fast-mfma-d": R.MATH_FAST_MFMA_D, "fast-mfma-e": R.MATH_FAST_MFMA_E, "fast-mfma-f": R.MATH_FAST_MFMA_F}[args.math]
+            "fast-mfma-f": R.MATH_FAST_MFMA_F}[args.math]
     cfg = R.wbfm_config(block_len=BLOCK_LEN, math=math_code, **cfg_kw)
     S, B = args.streams, args.blocks
     batch = R.BatchDemod(cfg, S, device=local)
@@ -784,7 +784,7 @@ def main():
                 mbytes = S * B * BLOCK_LEN + int(mlens.sum().item()) * 2
                 modes_leg[mname] = {
                     "workload": "%d concurrent %s streams per GPU x %d blocks" % (S, "2.4 Msps mono WBFM" if mname == "mono" else "200 ksps narrow-FM mono", B),
-                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_D: "fast-mfma-d", R.MATH_FAST_MFMA_F: "fast-mfma-f"}.get(mb.math, str(mb.math)),
+                    "kernel_family": {R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_F: "fast-mfma-f"}.get(mb.math, str(mb.math)),
                     "steps": args.steps, "kernel_ms": round(mk, 4), "ms_per_step": round(mwall / args.steps * 1e3, 4),
                     "value": round(samples_per_step * args.steps / mwall / 1e6, 1), "unit": "Msamples/s",
                     "algorithmic_bytes_per_launch": mbytes, "achieved_gbs": round(mbytes / (mk * 1e-3) / 1e9, 1),
@@ -821,7 +821,6 @@ def main():
             "vs_baseline": None,
             "dtype": ("f32" if batch.math in (R.MATH_EXACT, R.MATH_FAST_VALU) else
                       "f32 (stage A: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA else
-                      "f32 (stages A, C: int8-limb fixed point, exact sums)" if batch.math == R.MATH_FAST_MFMA_C else
                       "f32 (stages A, C, D: int8-limb fixed point, exact sums)" if stereo else "f32 (stages A, D: int8-limb fixed point, exact sums)"),
             "data": ("synthetic FM broadcast per stream (stereo multiplex: 19 kHz pilot + L-R DSB, tones, +-75 kHz)"
                      if args.data == "fm" and args.mode != "nfm" else
@@ -835,14 +834,11 @@ def main():
                  "(rate_in 25k -> 12.5k PCM), IQ resident in HBM" % (S, B, BLOCK_LEN)),
                 "streams_per_gpu": S, "blocks_per_step": B, "math": args.math,
                 # what ran: the kernel family FMD_MATH_FAST resolved to, and which stages used the matrix pipe
-                "kernel_family": {R.MATH_EXACT: "exact", R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma",
-                                  R.MATH_FAST_MFMA_C: "fast-mfma-c", R.MATH_FAST_MFMA_D: "fast-mfma-d", R.MATH_FAST_MFMA_E: "fast-mfma-e", R.MATH_FAST_MFMA_F: "fast-mfma-f"}.get(batch.math, str(batch.math)),
-                "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_C, R.MATH_FAST_MFMA_D, R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_F),
-                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)", R.MATH_FAST_MFMA_C: "A (i8 decimator) + C (i8 MPX filters)",
-                                R.MATH_FAST_MFMA_D: ("A (i8 decimator) + C (i8 MPX filters) + D (i8 second-stage low-pass at every sample)" if stereo else
-                                                     "A (i8 decimator) + D (i8 low-pass at every sample)"),
-                                R.MATH_FAST_MFMA_E: "A (i8 decimator) + C (i8 pilot and L-R filters) + D (i8 second-stage low-pass of L-R at every sample) + the L+R chain as one i8 filter fm * fm",
-                                R.MATH_FAST_MFMA_F: "A (i8 decimator) + C (i8 pilot and L-R filters) + D (i8 decimating second stage at the emit instants: the composite L+R filter fm * fm and fm over (L-R) x carrier)"}.get(batch.math, "none"),
+                "kernel_family": {R.MATH_EXACT: "exact", R.MATH_FAST_VALU: "fast-valu", R.MATH_FAST_MFMA: "fast-mfma", R.MATH_FAST_MFMA_F: "fast-mfma-f"}.get(batch.math, str(batch.math)),
+                "mfma": batch.math in (R.MATH_FAST_MFMA, R.MATH_FAST_MFMA_F),
+                "mfma_stages": {R.MATH_FAST_MFMA: "A (i8 decimator)",
+                                R.MATH_FAST_MFMA_F: ("A (i8 decimator) + C (i8 pilot and L-R filters) + D (i8 decimating second stage at the emit instants: the composite L+R filter fm * fm and fm over (L-R) x carrier)"
+                                                     if stereo else "A (i8 decimator) + D (i8 decimating low-pass at the emit instants)")}.get(batch.math, "none"),
                 "sharding": "streams/%d" % world, "kernel": batch.kernel_name(),
                 "untimed_launches_before_timing": max(args.preheat, args.warmup),
             },

@@ -165,39 +165,34 @@ void fmd_demod_release(struct demod_state *d);
 
 /* arithmetic contract */
 #define FMD_MATH_EXACT 0  /* reference operation order, unfused mul/add: bit-exact PCM */
-#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernels of this build for the configuration - FMD_MATH_FAST_MFMA_E
-                             (or _D, _C) for 90-tap stereo with whole tiles (block_len a multiple of 8192), FMD_MATH_FAST_MFMA otherwise;
+#define FMD_MATH_FAST 1   /* PCM within +-1 LSB: the fastest kernel family of this build for the configuration - FMD_MATH_FAST_MFMA_F where it
+                             applies, FMD_MATH_FAST_MFMA otherwise (FMD_MATH_FAST_VALU for a caller's decimator taps beyond the 26-bit form);
                              a caller who wants a particular family names it here instead (the library reads no environment
                              variable for this).  fmd_batch_math() says what a batch runs.  Sharing the device with other
                              MFMA kernels: one packed-fp32 instruction form computed wrong results beside them (round 3); it is
                              gone from the kernels, and every build's device code is linted for it (tools/isa_lint.py over the
-                             disassembly of the built library, run by the Makefile) - profiles/r04_pk_opsel_hazard.md.  The
+                             disassembly of the built library, run by the Makefile) - profiles/archive/r04_pk_opsel_hazard.md.  The
                              hazard is an empirical description of undocumented hardware behaviour: tests/test_gpu_neighbour.py
                              and tests/test_gpu_coresidency.py are the standing check. */
 #define FMD_MATH_FAST_VALU 2   /* +-1 LSB, vector ALU only: fused multiply-adds in the reference's summation order */
 #define FMD_MATH_FAST_MFMA 3   /* +-1 LSB, matrix pipe beside the vector ALU: the /8 decimator as exact int8 products
-                                  of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8) */
-#define FMD_MATH_FAST_MFMA_C 4 /* ... and, for 90-tap stereo, the three MPX filters as banded-Toeplitz products of int8 limbs
-                                  (samples round(v 2^20), taps round(h 2^qf), exact integer sums) on the same opcode: the
-                                  round 4's default of FMD_MATH_FAST; other configurations run
-                                  FMD_MATH_FAST_MFMA under this name */
-#define FMD_MATH_FAST_MFMA_D 5 /* ... and the second-stage low-pass of the stereo resampler: evaluated at every sample on the
-                                  matrix pipe from int8 limbs of {L+R, (L-R) x carrier}, the emit instants selected afterwards
-                                  (needs rate_out >= 4 rate_out2): the default of FMD_MATH_FAST where it applies; other
-                                  configurations run FMD_MATH_FAST_MFMA_C / _MFMA under this name */
-#define FMD_MATH_FAST_MFMA_E 6 /* ... with the L+R channel's two low-passes (src/rtl_fm_player.c:545, :588: the fm filter over the
-                                  discriminator ring, then again over the bm ring at the emit instants) as ONE 179-tap filter fm * fm
-                                  over the discriminator output - a linear chain needs no intermediate: 12 matrix instructions, a
-                                  join, a limb split and three limb arrays per tile less.  90-tap stereo where _MFMA_D applies: the
-                                  default of FMD_MATH_FAST there since round 5; 128-tap mono and everything else run what
-                                  FMD_MATH_FAST_MFMA_D runs */
-
-#define FMD_MATH_FAST_MFMA_F 7 /* ... with the stereo second stage (the composite L+R filter and fm over (L-R) x carrier) evaluated at the
-                                  resampler's emit instants only, as the reference does (src/rtl_fm_player.c:570-598): a decimating banded
-                                  product - rows = sixteen consecutive frames, columns = (group of sixteen frames, sample limb) - 32 matrix
-                                  instructions per tile where the full-rate form took 60.  Needs 16 rate_out a multiple of 4 rate_out2 with
-                                  4 <= rate_out / rate_out2 <= 6.25 (300 k, 240 k, 192 k -> 48 k); the default of FMD_MATH_FAST there
-                                  since round 6; everything else runs what FMD_MATH_FAST_MFMA_E runs */
+                                  of the IQ bytes with 26-bit fixed-point taps (v_mfma_i32_16x16x64_i8); any filter size, ragged tiles */
+#define FMD_MATH_FAST_MFMA_F 7 /* +-1 LSB, every stage that has a matrix form there, in int8-limb fixed point with exact integer sums
+                                  (samples round(v 2^20), taps round(h 2^qf)).  90-tap stereo: the pilot and L-R filters at full rate
+                                  (src/rtl_fm_player.c:538-566), the L+R channel's two low-passes (:545 / :560, :588) as ONE 179-tap
+                                  filter fm * fm and the second stage of L-R, both evaluated at the resampler's emit instants only, as
+                                  the reference does (:570-598): a decimating banded product - rows = sixteen consecutive frames,
+                                  columns = (group of sixteen frames, sample limb).  128-tap mono / narrow FM: the fm low-pass likewise
+                                  (:500-532).  Needs whole tiles (block_len a multiple of 8192), sixteen frames a whole number P of
+                                  samples, P a multiple of four (stereo: 64 .. 100 - 300 k, 240 k, 192 k -> 48 k; mono: 32 .. 128), and
+                                  the fixed-point error estimates of DESIGN.md section 2a below 0.15 LSB (volume up to ~8 at 300 k; narrow
+                                  FM up to ~1.7); other configurations run FMD_MATH_FAST_MFMA under this name */
+/* retired in round 6 (tools/experiments/retired_round5_families.inc): the intermediate matrix-pipe families of rounds 4 and 5 - stage C alone
+ * (_MFMA_C), the second stage at every sample (_MFMA_D), the composite L+R filter at every sample (_MFMA_E).  The names are accepted and mean
+ * FMD_MATH_FAST. */
+#define FMD_MATH_FAST_MFMA_C 4
+#define FMD_MATH_FAST_MFMA_D 5
+#define FMD_MATH_FAST_MFMA_E 6
 
 typedef struct fmd_config {
   int32_t rate_in;        /* demod_state.rate_in                               */
@@ -211,7 +206,7 @@ typedef struct fmd_config {
   float volume;           /* demod_state.volume                                */
   int32_t block_len;      /* bytes of u8 IQ per block (reference: 262144);     */
                           /* multiple of 16, >= 64                             */
-  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_C / _MFMA_D / _MFMA_E / _MFMA_F) */
+  int32_t math;           /* FMD_MATH_EXACT / FMD_MATH_FAST (/ _VALU / _MFMA / _MFMA_F) */
 } fmd_config;
 
 /* Filter tables; fmd_design_taps() fills them exactly as init_lp_f32 /
@@ -261,8 +256,8 @@ void fmd_batch_destroy(fmd_batch *b);
 /* int16 slots per (stream, block) in the PCM buffer (multiple of 8). */
 int fmd_batch_pcm_stride(const fmd_batch *b);
 int fmd_batch_n_streams(const fmd_batch *b);
-/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA, FMD_MATH_FAST_MFMA_C, _MFMA_D or _MFMA_E (FMD_MATH_FAST
- * in the configuration resolves to one of the last five at creation; a named family the configuration cannot run resolves likewise). */
+/* The kernel family this batch runs: FMD_MATH_EXACT, FMD_MATH_FAST_VALU, FMD_MATH_FAST_MFMA or FMD_MATH_FAST_MFMA_F (FMD_MATH_FAST
+ * in the configuration resolves to one of the last three at creation; a named family the configuration cannot run resolves likewise). */
 int fmd_batch_math(const fmd_batch *b);
 /* The same question without a device or a batch: the family fmd_batch_create would run for this configuration (and these taps; NULL:
  * fmd_design_taps), or a negative status for a configuration it would refuse. */

@@ -13,11 +13,10 @@ MATH_EXACT = 0
 MATH_FAST = 1          # the fastest +-1 LSB family of this build for the configuration
 MATH_FAST_VALU = 2     # +-1 LSB, vector ALU only
 MATH_FAST_MFMA = 3     # +-1 LSB, /8 decimator on the matrix pipe
-MATH_FAST_MFMA_C = 4   # ... and the three 90-tap stereo MPX filters there too (int8 limbs)
-MATH_FAST_MFMA_D = 5   # ... and the stereo resampler's second-stage low-pass (at every sample, emit instants selected)
-MATH_FAST_MFMA_E = 6   # ... with the L+R chain (fm over the discriminator ring, fm again over the bm ring) as one 179-tap filter fm * fm
-MATH_FAST_MFMA_F = 7   # ... with the stereo second stage at the resampler's emit instants only (decimating banded product; 16 rate_out a multiple of 4 rate_out2)
-FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_C, MATH_FAST_MFMA_D, MATH_FAST_MFMA_E, MATH_FAST_MFMA_F)
+MATH_FAST_MFMA_F = 7   # ... and every other stage that has a matrix form: 90-tap stereo (pilot / L-R filters at full rate, the composite L+R filter and the second
+                       # stage at the emit instants), 128-tap mono (stage D at the emit instants); what MATH_FAST resolves to where it applies
+MATH_FAST_MFMA_C, MATH_FAST_MFMA_D, MATH_FAST_MFMA_E = 4, 5, 6   # retired in round 6: accepted, mean MATH_FAST
+FAST_MATHS = (MATH_FAST_VALU, MATH_FAST_MFMA, MATH_FAST_MFMA_F)
 MAXIMUM_BUF_LENGTH = 16 * 16384
 
 

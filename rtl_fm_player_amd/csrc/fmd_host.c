@@ -346,14 +346,12 @@ static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
   return 3.1415927 * sm < 7.9 && 3.1415927 * ss < 7.9;
 }
 
-/* FMD_MATH_FAST_MFMA_E: the L+R chain of the stereo path as ONE filter.  The reference low-passes the discriminator output with fm into the
+/* The L+R chain of the stereo path as ONE filter (FMD_MATH_FAST_MFMA_F).  The reference low-passes the discriminator output with fm into the
  * bm ring at every sample (src/rtl_fm_player.c:545, :560) and low-passes that ring with fm again at the emit instants (:588): with no
  * non-linear step between them the two are the 179-tap filter g = fm * fm over the discriminator output.  g in double from the float taps,
  * T_g = round(g 2^qf) in three balanced int8 limbs like every filter of the matrix-pipe stages; the same bound on the weight classes
- * (accumulators read as floats) and the same error estimate as stage D's (one quantisation of the samples instead of two).  The kernel's
- * window holds 192 samples for 16 shifted rows: taps 177 and 178 (fm[0]^2 and 2 fm[0] fm[1]) are missing in row 0, tap 178 in row 1 -
- * their weight is part of the estimate. */
-static int build_lr_composite(const fmd_taps *t, fmdk_params *k, int short_window) {
+ * (accumulators read as floats) and the same error estimate as stage D's (one quantisation of the samples instead of two). */
+static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
   if (k->size != 90) return -1;
   double g[179];
   for (int u = 0; u < 179; u++) {
@@ -379,13 +377,13 @@ static int build_lr_composite(const fmd_taps *t, fmdk_params *k, int short_windo
     if (u < 90) k->gq[u] = (int32_t)E;
   }
   if (128.0 * sum_abs >= 4194304.0 - 65536.0) return -1;
-  /* error estimate in LSB (stage_d_error_lsb's three terms for 179 taps) + the two end taps rows 0 and 1 lack, at full deviation */
+  /* error estimate in LSB: stage_d_error_lsb's three terms for 179 taps */
   const double c0 = ldexp(1.0, 12 - qf);
   const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * 179.0) * 74.0 * 74.0;
   const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
   const double taps = sqrt(179.0) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
-  const double ends = short_window ? (fabs(g[177]) + fabs(g[178])) * 1.8 : 0.0;   /* (_MFMA_F's window holds every tap of every row) */
-  if (fabs((double)k->coef) * (sqrt(dropped * dropped + samples * samples + taps * taps) + ends) > FMD_STAGE_D_MAX_LSB) return -1;
+  /* (the decimating form's window holds every tap of every row; round 5's full-rate form lacked the last two in two of sixteen rows and carried a term for them) */
+  if (fabs((double)k->coef) * sqrt(dropped * dropped + samples * samples + taps * taps) > FMD_STAGE_D_MAX_LSB) return -1;
   k->g_qf = qf;
   k->g_scale = (float)ldexp(1.0, 12 - qf);
   k->g_unit = (float)ldexp(1.0, -qf);
@@ -563,68 +561,45 @@ static void fill_params(fmd_batch *b) {
 static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *taps) {
   int rc = 0;
   b->cfg = *cfg;
-  /* FMD_MATH_FAST = the fastest +-1 LSB kernel family for the configuration (a caller who wants a particular one names it in
-   * fmd_config.math; FMD_MFMA is read by tuning builds only) */
-  if (b->cfg.math == FMD_MATH_FAST) {
+  /* FMD_MATH_FAST = the fastest +-1 LSB kernel family for the configuration: FMD_MATH_FAST_MFMA_F where it applies, else FMD_MATH_FAST_MFMA, else (a
+   * caller's decimator taps beyond the 26-bit form) FMD_MATH_FAST_VALU.  The names of the families round 6 retired (_MFMA_C / _D / _E: include/fmdemod_mi355x.h)
+   * are accepted and mean FMD_MATH_FAST.  FMD_MFMA is read by tuning builds only. */
+  if (b->cfg.math == FMD_MATH_FAST || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D || b->cfg.math == FMD_MATH_FAST_MFMA_E) {
     const char *e_m = tuning_env("FMD_MFMA");
-    const int sel = e_m ? atoi(e_m) : 5;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2: stages A and C, 3: stages A, C
-                                                     and D, 4 (default): ... with the stereo L+R chain as one composite filter (90-tap
-                                                     stereo with whole tiles; what a configuration cannot run resolves downwards, see below) */
-    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 2 ? FMD_MATH_FAST_MFMA_C : sel == 1 ? FMD_MATH_FAST_MFMA : sel == 3 ? FMD_MATH_FAST_MFMA_D : sel == 4 ? FMD_MATH_FAST_MFMA_E : FMD_MATH_FAST_MFMA_F;
+    const int sel = e_m ? atoi(e_m) : 2;          /* 0: vector ALU only, 1: stage A on the matrix pipe, 2 (default): every stage that has a matrix form */
+    b->cfg.math = sel == 0 ? FMD_MATH_FAST_VALU : sel == 1 ? FMD_MATH_FAST_MFMA : FMD_MATH_FAST_MFMA_F;
   }
   if (taps) b->taps = *taps;
   else if ((rc = fmd_design_taps(cfg, &b->taps))) return rc;
   b->pcm_stride = (max_result_len(cfg) + 7) & ~7;
   fill_params(b);
-  const int want_f = b->cfg.math == FMD_MATH_FAST_MFMA_F;   /* _F is _E with the second stage at the emit instants only: _E's conditions first */
-  const int want_e = want_f || b->cfg.math == FMD_MATH_FAST_MFMA_E;
-  if (want_e) b->cfg.math = FMD_MATH_FAST_MFMA_D;   /* _E is _D with the L+R chain as one filter: the same conditions first */
-  if (b->cfg.math == FMD_MATH_FAST_MFMA_D) {
-    /* stages C and D on the matrix pipe: what stage C needs (below) and stage_d_on_matrix_pipe; otherwise stage C alone.
-     * 128-tap mono: stage D on the matrix pipe under the same name (there is no stage C), otherwise stage A alone. */
+  if (b->cfg.math == FMD_MATH_FAST_MFMA_F) {
+    /* What _MFMA_F needs; a configuration that lacks any of it runs the stage-A family, also when the caller named this one (it is a speed choice inside
+     * one +-1 LSB contract).  Whole tiles (block_len a multiple of 8192 bytes) and the resampler on; the fixed-point forms of the filters fit their
+     * accumulators (build_ci_scales*); rate_out >= 4 rate_out2 (stereo) / 2 rate_out2 (mono), the kernels' magic numbers exist and the second stage's
+     * error estimate stays below FMD_STAGE_D_MAX_LSB (stage_d_on_matrix_pipe; stereo: the composite L+R filter's likewise, build_lr_composite); and
+     * sixteen frames are a whole number P of samples, P a multiple of four (the groups' sample windows start P c - K0 bytes into the limb arrays: dword
+     * reads) with the window K0 + P inside the K slices the kernels run: P <= 100 for stereo (five slices for the composite filter, three for fm),
+     * 32 .. 128 for mono (four; below 64 a tile holds more than eight groups of sixteen frames: a column per group, fmdk_params.dec_wide). */
     const int whole = b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0;
-    if (b->cfg.mode == 1) {
-      if (!(whole && build_ci_scales_mono(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp)))
-        b->cfg.math = FMD_MATH_FAST_MFMA;
-      else if (want_f) {
-        /* the decimating form (resample_mono_dec): sixteen frames are P samples, P a multiple of four in 32 .. 128 (window 128 + P <= 256: four K slices);
-         * below 64 a tile holds more than eight groups of sixteen frames: a column per group */
-        const long long p16 = 16LL * b->kp.fast;
-        if (p16 % b->kp.slow == 0 && (p16 / b->kp.slow) % 4 == 0 && p16 / b->kp.slow >= 32 && p16 / b->kp.slow <= 128) {
-          b->kp.dec_p = (int32_t)(p16 / b->kp.slow);
-          b->kp.dec_wide = b->kp.dec_p < 64;
-          b->cfg.math = FMD_MATH_FAST_MFMA_F;
-        }
-      }
-    } else if (!(b->cfg.mode == 2 && whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 &&
-                 stage_d_on_matrix_pipe(&b->taps, &b->kp)))
-      b->cfg.math = FMD_MATH_FAST_MFMA_C;
-    else if (want_e && b->cfg.mode == 2) {
-      /* the decimating second stage (resample_tile_dec): sixteen frames are a whole number P of samples, P a multiple of four (the groups' sample
-       * windows start P c - K0 bytes into the limb arrays: dword reads) and at most 100 (window K0 + P: five K slices for the composite filter,
-       * three for fm); P >= 64 is rate_out >= 4 rate_out2, which _MFMA_D has checked */
-      const long long p16 = 16LL * b->kp.fast;
-      const int dec = want_f && p16 % b->kp.slow == 0 && (p16 / b->kp.slow) % 4 == 0 && p16 / b->kp.slow >= 64 && p16 / b->kp.slow <= 100;
-      if (dec && build_lr_composite(&b->taps, &b->kp, 0) == 0) {
-        b->kp.dec_p = (int32_t)(p16 / b->kp.slow);
-        b->cfg.math = FMD_MATH_FAST_MFMA_F;
-      } else if (build_lr_composite(&b->taps, &b->kp, 1) == 0) {
-        b->cfg.math = FMD_MATH_FAST_MFMA_E;
-      }
+    const long long p16 = 16LL * b->kp.fast, P = (b->kp.slow > 0 && p16 % b->kp.slow == 0) ? p16 / b->kp.slow : 0;
+    int ok = 0;
+    if (b->cfg.mode == 1)
+      ok = whole && build_ci_scales_mono(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp) && P % 4 == 0 && P >= 32 && P <= 128;
+    else if (b->cfg.mode == 2)
+      ok = whole && build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0 && stage_d_on_matrix_pipe(&b->taps, &b->kp) && P % 4 == 0 && P >= 64 && P <= 100 &&
+           build_lr_composite(&b->taps, &b->kp) == 0;
+    if (ok) {
+      b->kp.dec_p = (int32_t)P;
+      b->kp.dec_wide = b->cfg.mode == 1 && P < 64;
+    } else {
+      b->cfg.math = FMD_MATH_FAST_MFMA;
     }
   }
-  if (b->cfg.math == FMD_MATH_FAST_MFMA_C) {
-    /* stage C on the matrix pipe: 90-tap stereo with whole tiles (block_len a multiple of 8192 bytes); anything else runs the
-     * stage-A-only family, also when the caller named this one (it is a speed choice inside one +-1 LSB contract) */
-    if (!(b->cfg.mode == 2 && b->cfg.rate_out2 > 0 && (b->cfg.block_len % (16 * FMDK_TILE)) == 0 &&
-          build_ci_scales(&b->taps, b->cfg.size, &b->kp) == 0))
-      b->cfg.math = FMD_MATH_FAST_MFMA;
-  }
-  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_C || b->cfg.math == FMD_MATH_FAST_MFMA_D ||
-      b->cfg.math == FMD_MATH_FAST_MFMA_E || b->cfg.math == FMD_MATH_FAST_MFMA_F) {
+  if (b->cfg.math == FMD_MATH_FAST_MFMA || b->cfg.math == FMD_MATH_FAST_MFMA_F) {
     /* caller-supplied decimator taps too large for the 26-bit fixed-point form: the vector-ALU kernels take any taps */
     if (build_a_tab(&b->taps, b->cfg.offset_tuning != 0, &b->kp) != 0) {
-      if (cfg->math != FMD_MATH_FAST) { return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }
+      if (cfg->math == FMD_MATH_FAST_MFMA || cfg->math == FMD_MATH_FAST_MFMA_F) { return fail(FMD_E_UNSUPPORTED, "decimator taps beyond +-0.1245: FMD_MATH_FAST_MFMA needs |fb| < 2^-3.005"); }
       b->cfg.math = FMD_MATH_FAST_VALU;
     }
   }

@@ -20,13 +20,10 @@ def lcg40():
     return buf
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma_c", "mfma_d", "mfma_e", "mfma_f"])
+@pytest.fixture(params=["valu", "mfma", "mfma_f"])
 def fast_math(request):
-    """The +-1 LSB kernel families of the library: vector ALU only, stage A on the matrix pipe (what MATH_FAST resolves to for
-    mono / NFM / generic filter sizes), and stages A + C on the matrix pipe (what it resolves to for 90-tap stereo with whole tiles;
-    other configurations run the stage-A family under that name), and stages A + C + D (the default for 90-tap stereo at
-    rate_out >= 4 rate_out2 up to round 5's first half), and the same with the L+R chain as one composite filter (mfma_e: today's default there;
-    mono and everything else run what mfma_d runs under that name), and that with the second stage at the emit instants only (mfma_f: round 6's
-    default where sixteen frames are a whole number of samples - 300 k, 240 k, 192 k -> 48 k; the rest runs mfma_e's kernels under that name)."""
+    """The +-1 LSB kernel families of the library: vector ALU only; stage A on the matrix pipe (what MATH_FAST resolves to for generic filter sizes, ragged
+    tiles and rates the decimating second stage does not cover); and every stage that has a matrix form (mfma_f: 90-tap stereo and 128-tap mono where
+    sixteen frames are a whole number of samples - 300 k, 240 k, 192 k -> 48 k, 25 k -> 12.5 k; other configurations run the stage-A family under that name)."""
     import rtl_fm_player_amd as R
-    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E, "mfma_f": R.MATH_FAST_MFMA_F}[request.param]
+    return {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_f": R.MATH_FAST_MFMA_F}[request.param]

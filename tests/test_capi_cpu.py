@@ -77,8 +77,7 @@ def test_design_taps_equals_oracle():
     dict(math=8), dict(math=-1),
     # the +-1 LSB kernels evaluate the de-emphasis with powers of lambda: they need a contraction
     dict(math=R.MATH_FAST, deemph_lambda=1.0), dict(math=R.MATH_FAST_VALU, deemph_lambda=0.0),
-    dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5), dict(math=R.MATH_FAST_MFMA_D, deemph_lambda=1.0),
-    dict(math=R.MATH_FAST_MFMA_E, deemph_lambda=1.0), dict(math=R.MATH_FAST_MFMA_F, deemph_lambda=1.0),
+    dict(math=R.MATH_FAST_MFMA, deemph_lambda=-0.5), dict(math=R.MATH_FAST_MFMA_C, deemph_lambda=1.5), dict(math=R.MATH_FAST_MFMA_F, deemph_lambda=1.0),
 ])
 def test_bad_configs_are_rejected(bad):
     bad = dict(bad)
@@ -94,7 +93,7 @@ def test_bad_configs_are_rejected(bad):
 @pytest.mark.parametrize("ok", [
     dict(math=R.MATH_EXACT, deemph_lambda=1.0), dict(math=R.MATH_EXACT, deemph_lambda=0.0),   # the exact kernels take any lambda
     dict(math=R.MATH_FAST, deemph=False, deemph_lambda=1.0),                                  # ... and it is not read with de-emphasis off
-    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_C), dict(math=R.MATH_FAST_MFMA_D), dict(math=R.MATH_FAST_MFMA_E), dict(math=R.MATH_FAST_MFMA_F),
+    dict(math=R.MATH_FAST_VALU), dict(math=R.MATH_FAST_MFMA), dict(math=R.MATH_FAST_MFMA_F), dict(math=R.MATH_FAST_MFMA_E),
 ])
 def test_good_configs_are_accepted(ok):
     lam = ok.pop("deemph_lambda", None)
@@ -106,24 +105,21 @@ def test_good_configs_are_accepted(ok):
 
 
 @pytest.mark.parametrize("kw,want", [
-    # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2: stages A, C, D on the matrix pipe, the L+R chain as one composite filter ...
-    # ... and, where sixteen frames are a whole number P of samples (P a multiple of four in 64 .. 100), the second stage at the emit instants only
+    # 90-tap stereo, whole tiles, rate_out >= 4 rate_out2 and sixteen frames a whole number P of samples (a multiple of four up to 100): every stage on the
+    # matrix pipe - the pilot and L-R filters at full rate, the composite L+R filter and the second stage at the emit instants
     (dict(rate_in=300000, rate_out2=48000, mode=2), "MFMA_F"), (dict(rate_in=192000, rate_out2=48000, mode=2), "MFMA_F"),
     (dict(rate_in=240000, rate_out2=48000, mode=2, volume=3.0), "MFMA_F"),
-    # (P = 16 x 220 / 48 is no integer; 16 x 330 / 48 = 110 needs a sixth K slice: the full-rate second stage)
-    (dict(rate_in=220000, rate_out2=48000, mode=2), "MFMA_E"), (dict(rate_in=330000, rate_out2=48000, mode=2), "MFMA_E"),
-    # ... while the composite's error estimate stays below 0.15 LSB: the full-rate form's window lacks the two end taps in two of sixteen rows
-    # (0.39 at volume 8 -> the two-stage form), the decimating form's holds them all (volume 8 passes, 12 does not)
-    (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_F"), (dict(rate_in=300000, rate_out2=48000, mode=2, volume=12.0), "MFMA_D"),
-    (dict(rate_in=220000, rate_out2=48000, mode=2, volume=8.0), "MFMA_D"),
-    # rate_out < 4 rate_out2: the selection of stage D does not apply - stage C alone
-    (dict(rate_in=171000, rate_out2=44100, mode=2), "MFMA_C"),
+    # ... while the second stage's error estimates stay below 0.15 LSB: volume 8 passes at 300 k (the window holds every tap), 12 does not
+    (dict(rate_in=300000, rate_out2=48000, mode=2, volume=8.0), "MFMA_F"), (dict(rate_in=300000, rate_out2=48000, mode=2, volume=12.0), "MFMA"),
+    # P = 16 x 220 / 48 is no integer; 16 x 330 / 48 = 110 needs a sixth K slice; rate_out < 4 rate_out2: stage A only
+    (dict(rate_in=220000, rate_out2=48000, mode=2), "MFMA"), (dict(rate_in=330000, rate_out2=48000, mode=2), "MFMA"),
+    (dict(rate_in=171000, rate_out2=44100, mode=2), "MFMA"),
     # other filter sizes, ragged tiles: stage A only
     (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), "MFMA"), (dict(rate_in=300000, rate_out2=48000, mode=2, block_len=16000), "MFMA"),
-    # 128-tap mono / narrow FM: stage D on the matrix pipe at rate_out >= 2 rate_out2 ...
-    # (where sixteen frames are a whole number of samples - a multiple of four in 32 .. 128 - at the emit instants only: _MFMA_F)
+    # 128-tap mono / narrow FM: stage D on the matrix pipe at the emit instants where P is a multiple of four in 32 .. 128 ...
     (dict(rate_in=300000, rate_out2=48000, mode=1), "MFMA_F"), (dict(rate_in=25000, rate_out2=12500, mode=1), "MFMA_F"),
-    (dict(rate_in=96000, rate_out2=32000, mode=1), "MFMA_F"), (dict(rate_in=100000, rate_out2=48000, mode=1), "MFMA_D"), (dict(rate_in=48000, rate_out2=32000, mode=1), "MFMA"),
+    (dict(rate_in=96000, rate_out2=32000, mode=1), "MFMA_F"), (dict(rate_in=384000, rate_out2=48000, mode=1), "MFMA_F"),
+    (dict(rate_in=100000, rate_out2=48000, mode=1), "MFMA"), (dict(rate_in=48000, rate_out2=32000, mode=1), "MFMA"),
     (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), "MFMA"),
     # ... while its fixed-point error estimate stays below 0.15 LSB: narrow FM's filter (largest tap 0.58) at volume 3 and 8 does not
     (dict(rate_in=25000, rate_out2=12500, mode=1, volume=1.0), "MFMA_F"), (dict(rate_in=25000, rate_out2=12500, mode=1, volume=3.0), "MFMA"),
@@ -134,14 +130,11 @@ def test_good_configs_are_accepted(ok):
 def test_family_resolution_needs_no_device(kw, want):
     """What FMD_MATH_FAST (and the named family) resolves to is decided on the host before the device is touched (fmd_config_family):
     the rules of DESIGN.md section 1 / 2a, checked here without a GPU."""
-    code = {"MFMA_F": R.MATH_FAST_MFMA_F, "MFMA_E": R.MATH_FAST_MFMA_E, "MFMA_D": R.MATH_FAST_MFMA_D, "MFMA_C": R.MATH_FAST_MFMA_C, "MFMA": R.MATH_FAST_MFMA,
-            "VALU": R.MATH_FAST_VALU}[want]
-    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F):
+    code = {"MFMA_F": R.MATH_FAST_MFMA_F, "MFMA": R.MATH_FAST_MFMA, "VALU": R.MATH_FAST_VALU}[want]
+    # (the names of the families round 6 retired are accepted and mean MATH_FAST)
+    for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F, R.MATH_FAST_MFMA_C, R.MATH_FAST_MFMA_D, R.MATH_FAST_MFMA_E):
         assert R.config_family(R.wbfm_config(math=m, **kw)) == code, (kw, m)
-    # the families of round 5, named: what they were
-    short_window_fails = kw.get("volume", 0.4) >= 8.0 or kw["mode"] == 1       # (the full-rate composite filter's estimate with its two missing end taps; mono has no composite filter)
-    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_E, **kw)) == ((R.MATH_FAST_MFMA_D if short_window_fails else R.MATH_FAST_MFMA_E) if want == "MFMA_F" else code), kw
-    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA_D, **kw)) == (R.MATH_FAST_MFMA_D if want in ("MFMA_E", "MFMA_F") else code), kw
+    assert R.config_family(R.wbfm_config(math=R.MATH_FAST_MFMA, **kw)) == R.MATH_FAST_MFMA
     assert R.config_family(R.wbfm_config(math=R.MATH_EXACT, **kw)) == R.MATH_EXACT
     assert R.config_family(R.wbfm_config(math=R.MATH_FAST_VALU, **kw)) == R.MATH_FAST_VALU
 

@@ -77,3 +77,26 @@ def test_forced_collectives_with_one_rank():
     mp.spawn(_worker_forced, args=(1, port, out), nprocs=1, join=True)
     assert out[0] == {"world": 1, "elapsed_s": 0.5, "samples": 10, "backend": "gloo",
                       "per_rank": [{"samples": 10, "kernel_ns": 3, "checksum": 7}]}
+
+
+def test_node_bench_plan_matches_the_python_sharding():
+    """The C node driver (csrc/fmd_node_bench.c -P: no device touched) places streams like shard.py where the split is even, contiguously
+    and completely everywhere, and refuses a device without streams; BASELINE.json configs[3] = 2048 streams on 8 devices = 256 each."""
+    import json
+    import subprocess
+    import rtl_fm_player_amd as R
+    exe = os.path.join(os.path.dirname(R.library_path()), "fmd_node_bench")
+    if not os.path.exists(exe):
+        R.build_library()
+    for total, world in ((2048, 8), (2000, 8), (256, 1), (7, 2), (2049, 8)):
+        r = subprocess.run([exe, "-P", "-d", str(world), "-s", str(total)], capture_output=True, text=True, timeout=30)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout)
+        sh = d["shards"]
+        assert d["devices"] == world == len(sh) and d["streams"] == total and d["data_path_collectives"] == 0
+        assert sh[0]["first_stream"] == 0 and sum(x["streams"] for x in sh) == total
+        for a, b in zip(sh, sh[1:]):
+            assert b["first_stream"] == a["first_stream"] + a["streams"]
+        if total % world == 0:
+            assert [(x["first_stream"], x["streams"]) for x in sh] == [shard_streams(total, world, r_) for r_ in range(world)]
+    assert sh and subprocess.run([exe, "-P", "-d", "3", "-s", "2"], capture_output=True, text=True, timeout=30).returncode == 2

@@ -186,21 +186,17 @@ def test_default_family_falls_back_when_taps_do_not_fit_the_float_accumulators(R
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, **cfg_kw), 1)
     assert b.math == R.MATH_FAST_MFMA_F
     b.close()
-    # stage D on the matrix pipe selects at most one emit among four consecutive samples: rate_out >= 4 rate_out2, else stage C alone; its decimating
-    # form (_MFMA_F) where sixteen frames are a whole number of samples (a multiple of four up to 100), else the full-rate form (_MFMA_E)
-    for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_F), (dict(rate_in=220000, rate_out2=48000, mode=2), R.MATH_FAST_MFMA_E),
-                     (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA_C),
+    # the second stage on the matrix pipe needs sixteen frames to be a whole number of samples (a multiple of four: up to 100 for stereo, 32 .. 128 for mono)
+    # and rate_out >= 4 rate_out2 (stereo) / 2 rate_out2 (mono); everything else runs the stage-A family
+    for kw, want in ((CONFIGS["stereo_192k"], R.MATH_FAST_MFMA_F), (dict(rate_in=220000, rate_out2=48000, mode=2), R.MATH_FAST_MFMA),
+                     (dict(rate_in=171000, rate_out2=44100, mode=2), R.MATH_FAST_MFMA),
                      (dict(rate_in=300000, rate_out2=48000, mode=2, size=64), R.MATH_FAST_MFMA), (CONFIGS["mono_300k"], R.MATH_FAST_MFMA_F),
                      (CONFIGS["nfm_25k"], R.MATH_FAST_MFMA_F), (dict(rate_in=96000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA_F),
-                     (dict(rate_in=100000, rate_out2=48000, mode=1), R.MATH_FAST_MFMA_D),     # (16 x 100 / 48 is no integer: the full-rate stage D)
+                     (dict(rate_in=100000, rate_out2=48000, mode=1), R.MATH_FAST_MFMA),     # (16 x 100 / 48 is no integer)
                      (dict(rate_in=48000, rate_out2=32000, mode=1), R.MATH_FAST_MFMA), (dict(rate_in=240000, rate_out2=48000, mode=1, size=90), R.MATH_FAST_MFMA)):
-        for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F, R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_D):   # (_MFMA_E / _MFMA_D named: what they were in round 5)
+        for m in (R.MATH_FAST, R.MATH_FAST_MFMA_F, R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_D):   # (the retired names mean MATH_FAST)
             b = R.BatchDemod(R.wbfm_config(math=m, **kw), 1)
-            stereo_d = kw["mode"] == 2 and want in (R.MATH_FAST_MFMA_E, R.MATH_FAST_MFMA_F)
-            mono_f = kw["mode"] == 1 and want == R.MATH_FAST_MFMA_F          # (mono has no composite filter: _MFMA_E named runs _MFMA_D)
-            expect = (R.MATH_FAST_MFMA_D if (m == R.MATH_FAST_MFMA_D and stereo_d) else R.MATH_FAST_MFMA_E if (m == R.MATH_FAST_MFMA_E and stereo_d) else
-                      R.MATH_FAST_MFMA_D if (mono_f and m in (R.MATH_FAST_MFMA_D, R.MATH_FAST_MFMA_E)) else want)
-            assert b.math == expect, (kw, m, b.math)
+            assert b.math == want, (kw, m, b.math)
             b.close()
     b = R.BatchDemod(R.wbfm_config(math=R.MATH_FAST, block_len=16 * 1000, **cfg_kw), 1)      # ragged tiles: stage A only
     assert b.math == R.MATH_FAST_MFMA
@@ -243,7 +239,7 @@ def test_carried_state_matches_oracle(R, lcg40):
 def test_fast_carried_rings_match_the_oracle(R, lcg40, name, fast_math):
     """What a +-1 LSB launch leaves in the br / bm / bs rings (the drop-in surface mirrors them into the caller's struct lp_real) against the
     reference's rings: br in the reference's own bits where the hand-over recomputes it, bm and bs to a few steps of the 2^-20 grid the
-    matrix-pipe stages keep them on.  FMD_MATH_FAST_MFMA_E keeps NO bm ring while it runs (its L+R chain is one composite filter): the ring
+    matrix-pipe stages keep them on.  FMD_MATH_FAST_MFMA_F keeps NO bm ring while it runs (its L+R chain is one composite filter): the ring
     is made at the launch's end from the discriminator history, and met again at the next launch's start (lr_head_fix) - five one-block
     launches here, so the second to fifth start from a ring the launch before made."""
     nb = 5

@@ -128,7 +128,7 @@ def test_stage_d_stays_on_the_vector_alu_where_its_error_estimate_is_too_large(R
     for vol in (0.4, 8.0):                                   # 300 k stereo / mono: 0.08 - 0.09 LSB at volume 8
         for name in ("stereo_300k", "mono_300k"):
             b = R.BatchDemod(R.wbfm_config(block_len=BL, math=R.MATH_FAST, volume=vol, **CONFIGS[name]), 1)
-            # stereo at the default volume: the composite L+R filter on top (_MFMA_E); at volume 8 its estimate (0.39: the two end taps that
+            # (round 5's full-rate composite filter failed its estimate at volume 8 - 0.39: the two end taps that
             # two of sixteen rows lack) keeps the two-stage form
             want = R.MATH_FAST_MFMA_F    # (stereo: _MFMA_E with the second stage at the emit instants only - its window holds every tap, so its estimate passes at volume 8 as well; mono: _MFMA_D likewise)
             assert b.math == want, (name, vol, b.math)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel ms of the +-1 LSB kernel families of ONE build on the same device, interleaved, two rounds per mode.
 # Families are bench.py's --math names (fmd_config.math; the library reads no environment variable for this):
-# FAMILIES="fast-valu fast-mfma fast-mfma-c fast-mfma-d".   tools/ab_math.sh <tag> [modes...] [-- bench flags]
+# FAMILIES="fast-valu fast-mfma fast-mfma-f".   tools/ab_math.sh <tag> [modes...] [-- bench flags]
 TAG=$1; shift
 MODES=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do MODES+=("$1"); shift; done; [ "$1" = "--" ] && shift
 [ ${#MODES[@]} -eq 0 ] && MODES=(stereo mono nfm)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: the synthetic FM broadcast of bench.py (stereo multiplex with pilot, +-75 kHz) x volume, every +-1 LSB family against the oracle: the
-signal the headline is measured on, at the volumes around the composite L+R filter's gate (FMD_MATH_FAST_MFMA_E runs up to volume ~3 at 300 kHz).
+signal the headline is measured on, at the volumes around the composite L+R filter's gate (FMD_MATH_FAST_MFMA_F runs up to volume ~8 at 300 kHz).
 Prints per volume: the family each name resolved to, the worst |PCM difference| and how many values differ.   python tools/fm_volume_scan.py"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ from oracle import OracleStream
 BL, NB, NS = 262144, 4, 16
 dev = torch.device("cuda:0")
 iq = bench.synth_fm_iq(torch, dev, NS, NB * BL // 2, 2400000.0, True, 4242).cpu().numpy().reshape(NS, NB, BL)
-FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E, "mfma_f": R.MATH_FAST_MFMA_F}
+FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_f": R.MATH_FAST_MFMA_F}
 worst_all = 0
 for rate_in in (300000, 240000):
     for vol in (0.4, 1.0, 2.0, 2.5, 3.0, 3.5, 5.0, 8.0):

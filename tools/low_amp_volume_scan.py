@@ -13,7 +13,7 @@ BL = 262144
 NB, NS = 4, 8
 MODES = {"stereo": dict(rate_in=300000, rate_out2=48000, mode=2), "mono": dict(rate_in=300000, rate_out2=48000, mode=1),
          "nfm": dict(rate_in=25000, rate_out2=12500, mode=1)}
-FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_c": R.MATH_FAST_MFMA_C, "mfma_d": R.MATH_FAST_MFMA_D, "mfma_e": R.MATH_FAST_MFMA_E, "mfma_f": R.MATH_FAST_MFMA_F}
+FAMS = {"valu": R.MATH_FAST_VALU, "mfma": R.MATH_FAST_MFMA, "mfma_f": R.MATH_FAST_MFMA_F}
 worst_all = 0
 AMPS = [int(a) for a in os.environ.get("SCAN_AMPS", "1,2,3,4,6,10,20").split(",")]
 for amp in AMPS:

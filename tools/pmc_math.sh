@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box): tools/pmc_math.sh <tag> <family: fast-valu|fast-mfma|fast-mfma-c|fast-mfma-d> <mode> -> per-launch PMC means of the fused kernel for one kernel family
+# Usage (GPU box): tools/pmc_math.sh <tag> <family: fast-valu|fast-mfma|fast-mfma-f> <mode> -> per-launch PMC means of the fused kernel for one kernel family
 TAG=$1; F=$2; MODE=$3
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 for CNT in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU" \

@@ -28,7 +28,7 @@ def main():
     BL = 262144
     dev = torch.device("cuda:0")
     fam = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
-           "fast-mfma-c": R.MATH_FAST_MFMA_C, "fast-mfma-d": R.MATH_FAST_MFMA_D, "fast-mfma-e": R.MATH_FAST_MFMA_E, "fast-mfma-f": R.MATH_FAST_MFMA_F}[a.math]
+           "fast-mfma-f": R.MATH_FAST_MFMA_F}[a.math]
     cfg = R.wbfm_config(block_len=BL, math=fam,
                         **(dict(rate_in=25000, rate_out2=12500, mode=1) if a.mode == "nfm" else
                            dict(rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)))
