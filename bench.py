@@ -498,6 +498,10 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+POWER_BASE_W = 354.0        # package draw with every SIMD issuing s_nop at 2.4 GHz (profiles/r6b_power_price_live_operands.txt; 366 - 367 W on the devices of round 5)
+NJ_PER_BYTE = 0.124         # a device-to-device copy above that base, per byte moved (profiles/archive/r33_stream_power.txt)
+
+
 class PowerWatch:
     """Package power and shader clock of ONE device, read from its hwmon files (amdgpu: power1_input in microwatts, power1_cap,
     freq1_input in Hz) by a thread while a leg of the bench runs.  No rocm-smi process, no HIP call; silently absent where the files are
@@ -867,6 +871,21 @@ def main():
             out["parity"] = parity
         if sustained:
             out["sustained"] = sustained
+            pw = sustained.get("power")
+            if pw and pw.get("cap_w"):
+                # The energy books of one launch: what the package drew while the sustained leg ran x the kernel's time there, split
+                # into the base draw (every SIMD clocked and issuing s_nop: POWER_BASE_W, tools/ubench/power_price.hip), the bytes moved (NJ_PER_BYTE from
+                # a device-to-device copy, tools/stream_power.py, x the traffic of the committed profile or the algorithmic bytes) and the arithmetic
+                # (the rest).  bound_ms: the launch's energy at the cap - the time it would take if the cap were the only limit.
+                t_s = sustained["kernel_ms"] * 1e-3
+                joules = pw["package_w_mean"] * t_s
+                moved = out["roofline"]["traffic"] or algo_bytes
+                out["roofline"]["power"] = {
+                    "cap_w": pw["cap_w"], "package_w": pw["package_w_mean"], "sclk_mhz": pw["sclk_mhz_mean"], "base_w": POWER_BASE_W, "nJ_per_byte": NJ_PER_BYTE,
+                    "J_per_launch": round(joules, 4), "base_J": round(POWER_BASE_W * t_s, 4), "bytes_J": round(NJ_PER_BYTE * 1e-9 * moved, 4),
+                    "arithmetic_J": round(joules - POWER_BASE_W * t_s - NJ_PER_BYTE * 1e-9 * moved, 4),
+                    "bound_ms": round(joules / pw["cap_w"] * 1e3, 4), "kernel_ms": sustained["kernel_ms"],
+                    "note": "sustained leg; bound_ms = J_per_launch / cap_w; the kernel sits at the cap when package_w ~ cap_w and sclk below its 2400 MHz maximum"}
         if noise_leg:
             out["noise_input"] = noise_leg
         if quiet_leg:

@@ -262,6 +262,17 @@ int fmd_batch_math(const fmd_batch *b);
 /* The same question without a device or a batch: the family fmd_batch_create would run for this configuration (and these taps; NULL:
  * fmd_design_taps), or a negative status for a configuration it would refuse. */
 int fmd_config_family(const fmd_config *cfg, const fmd_taps *taps);
+/* What the fixed-point second stage of FMD_MATH_FAST_MFMA_F adds to a PCM value for this configuration, in LSB - whether or not the configuration runs it
+ * (`family` says what it resolves to): per filter (stereo: [0] the composite L+R filter fm * fm, 179 taps, [1] fm over (L-R) x carrier; mono: [0] fm) the
+ * rms ESTIMATE the family is gated on (limit_rms_lsb) and a worst-case BOUND with its three terms - samples rounded to 2^-20, taps rounded to 2^-qf, the
+ * limb pairs left out (csrc/fmd_host.c, fixed_point_error).  The other stages' differences to the reference (fused multiply-adds,
+ * v_rcp_f32, the exact redo of ill-conditioned samples) have no bound of this kind: tests/, the fuzz and the volume scans vouch for them.  No device needed. */
+typedef struct fmd_error_estimate {
+  int32_t family, filters;
+  struct { int32_t taps, qf; float rms_lsb, worst_lsb, worst_samples_lsb, worst_taps_lsb, worst_dropped_lsb; } f[2];
+  float limit_rms_lsb;
+} fmd_error_estimate;
+int fmd_config_error_estimate(const fmd_config *cfg, const fmd_taps *taps, fmd_error_estimate *out);
 /* How a launch is cut into time chunks (one worker wavefront each; results do not depend on it - the tests hold the
  * library to that through this call): workers_per_cu > 0 = cut until the grid offers that many workers per CU,
  * 0 = the kernels' own figure (default), < 0 = never cut (one worker per stream). */

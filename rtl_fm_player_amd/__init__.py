@@ -23,6 +23,7 @@ from .capi import (  # noqa: F401
     FmdStreamState,
     FmdTaps,
     build_library,
+    config_error_estimate,
     config_family,
     design_taps,
     device_count,

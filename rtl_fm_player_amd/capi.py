@@ -52,6 +52,15 @@ class FmdTaps(C.Structure):
                 ("fs", C.c_float * 128), ("swf", C.c_float), ("cwf", C.c_float)]
 
 
+class _FmdFilterError(C.Structure):
+    _fields_ = [("taps", C.c_int32), ("qf", C.c_int32), ("rms_lsb", C.c_float), ("worst_lsb", C.c_float),
+                ("worst_samples_lsb", C.c_float), ("worst_taps_lsb", C.c_float), ("worst_dropped_lsb", C.c_float)]
+
+
+class FmdErrorEstimate(C.Structure):
+    _fields_ = [("family", C.c_int32), ("filters", C.c_int32), ("f", _FmdFilterError * 2), ("limit_rms_lsb", C.c_float)]
+
+
 class FmdStreamState(C.Structure):
     _fields_ = [("tb", C.c_float * 48), ("pre_r", C.c_float), ("pre_j", C.c_float), ("pp", C.c_float),
                 ("deemph_l", C.c_float), ("deemph_r", C.c_float), ("acc", C.c_int32),
@@ -218,6 +227,15 @@ def config_family(cfg, taps=None):
     rc = lib().fmd_config_family(C.byref(cfg), C.byref(taps) if taps is not None else None)
     _check(rc if rc < 0 else 0, "fmd_config_family")
     return rc
+
+
+def config_error_estimate(cfg, taps=None):
+    """fmd_config_error_estimate as a dict: what the fixed-point second stage adds to a PCM value (rms estimate, worst-case bound and its terms, per
+    filter) and the family the configuration resolves to.  Needs no device."""
+    e = FmdErrorEstimate()
+    _check(lib().fmd_config_error_estimate(C.byref(cfg), C.byref(taps) if taps is not None else None, C.byref(e)), "fmd_config_error_estimate")
+    return {"family": e.family, "limit_rms_lsb": e.limit_rms_lsb,
+            "filters": [{k: getattr(e.f[i], k) for k, _ in _FmdFilterError._fields_} for i in range(e.filters)]}
 
 
 def _ptr(x):

@@ -312,27 +312,67 @@ static int build_ci_scales_mono(const fmd_taps *t, int size, fmdk_params *k) {
   return 0;
 }
 
-/* What stage D's fixed-point form adds to a PCM value, in LSB (rms estimate), for n taps of the fm filter at scale 2^qf and the batch's
- * PCM scale `coef` (volume x 32768): three independent terms -
- *   the limb pairs left out (tap limb + sample limb >= 3: weight 2^-24 of the sum's scale c0 = 2^(12 - qf); 2 n products of two limbs
- *     of rms 74 each),
- *   the samples' rounding to 2^-20 (uniform: 2^-21 / sqrt 3 per sample, through the filter: x sqrt(sum h^2)),
- *   the taps' rounding to 2^-qf (2^-(qf+1) / sqrt 3 per tap, n taps, samples of rms ~1.8 at most - a discriminator output uniform in +-pi).
- * Stage D's output IS the PCM value before de-emphasis and scaling, so these are its error in LSB after x coef.  300 k stereo / mono:
- * 0.004 at volume 0.4, 0.08 - 0.09 at volume 8 (max |difference| 1 LSB measured); 25 k narrow FM (largest tap 0.58: qf 23, c0 eight
- * times the 300 k filters'): 0.035 at volume 0.4, 0.09 at 1, 0.26 at 3 (still 1 LSB at most in 262 144 values) and 0.70 at volume 8,
- * where 3 LSB were measured (tools/low_amp_volume_scan.py, profiles/r5q_low_amp_volume_scan_before.txt).  Beyond 0.15 the
- * configuration keeps stage D on the vector ALU: five standard deviations stay below one step. */
-static double stage_d_error_lsb(const float *fm, int n, int qf, float coef) {
-  double sh2 = 0.0;
-  for (int u = 0; u < n / 2; u++) sh2 += 2.0 * (double)fm[u] * (double)fm[u];
-  const double c0 = ldexp(1.0, 12 - qf);
+/* What a second-stage filter's fixed-point form (taps T = round(h 2^qf) and samples q = round(x 2^20) in three balanced int8 limbs each, six of the nine limb
+ * pairs kept) adds to a PCM value, in LSB: the filter's output IS the PCM value before de-emphasis and scaling, so an error e in it is e x coef LSB
+ * (coef = volume x 32768).  Three terms, each as an rms ESTIMATE and as a worst-case BOUND from the filter's own taps and limbs:
+ *   the limb pairs left out (tap limb + sample limb >= 3): S3 = sum_k (t1 s2 + t2 s1) at weight c0 2^-24 and S4 = sum_k t2 s2 at c0 2^-32, c0 = 2^(12 - qf).
+ *     rms: 2 n products of two limbs of rms 74 each; bound: |sample limb| <= 128, so |S3| <= 128 sum_k (|t1| + |t2|), |S4| <= 128 sum_k |t2|;
+ *   the samples' rounding to 2^-20: rms 2^-21 / sqrt 3 per sample through the filter (x sqrt(sum h^2)); bound 2^-21 sum |h|;
+ *   the taps' rounding to 2^-qf: rms 2^-(qf+1) / sqrt 3 per tap, n taps, samples of rms ~1.8 at most (a discriminator output uniform in +-pi);
+ *     bound n 2^-(qf+1) pi (the L-R channel's samples are (L-R band) x carrier: the same range).
+ * 300 k stereo / mono: rms 0.004 at volume 0.4, 0.08 - 0.09 at volume 8 (max |difference| 1 LSB measured); 25 k narrow FM (largest tap 0.58: qf 23, c0
+ * eight times the 300 k filters'): 0.035 at volume 0.4, 0.09 at 1, 0.26 at 3 (still 1 LSB at most in 262 144 values) and 0.70 at volume 8, where 3 LSB
+ * were measured (profiles/archive/r5q_low_amp_volume_scan_before.txt).  The GATE is the rms estimate <= FMD_STAGE_D_MAX_LSB (ten standard deviations below
+ * one step: a statistical guarantee); the bound is reported (fmd_config_error_estimate) and is below half a step for the reference's
+ * default configurations. */
+typedef struct { double rms, worst_samples, worst_taps, worst_dropped; int qf, n; } stage_error;
+static stage_error fixed_point_error(const double *h, int n, int qf, double coef) {
+  stage_error e = {0.0, 0.0, 0.0, 0.0, qf, n};
+  double sh2 = 0.0, sabs = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int u = 0; u < n; u++) {
+    sh2 += h[u] * h[u];
+    sabs += fabs(h[u]);
+    const long long E = llround(h[u] * ldexp(1.0, qf));
+    const unsigned q = ((unsigned)(int)E + 0x808080u) ^ 0x808080u;
+    a1 += fabs((double)(signed char)(q >> 8));
+    a2 += fabs((double)(signed char)q);
+  }
+  const double c0 = ldexp(1.0, 12 - qf), ac = fabs(coef);
   const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * n) * 74.0 * 74.0;
   const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
   const double taps = sqrt((double)n) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
-  return fabs((double)coef) * sqrt(dropped * dropped + samples * samples + taps * taps);
+  e.rms = ac * sqrt(dropped * dropped + samples * samples + taps * taps);
+  e.worst_dropped = ac * c0 * (ldexp(1.0, -24) * 128.0 * (a1 + a2) + ldexp(1.0, -32) * 128.0 * a2);
+  e.worst_samples = ac * ldexp(1.0, -21) * sabs;
+  e.worst_taps = ac * (double)n * ldexp(1.0, -(qf + 1)) * 3.14159265358979;
+  return e;
 }
-#define FMD_STAGE_D_MAX_LSB 0.15
+static int taps_qf(const double *h, int n) {
+  double mx = 0.0;
+  for (int u = 0; u < n; u++) mx = fmax(mx, fabs(h[u]));
+  if (!(mx > 0.0) || !isfinite(mx)) return -1;
+  int qf = 40;
+  while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
+  return qf;
+}
+static void fm_full(const float *fm, int n, double *h) { for (int u = 0; u < n; u++) h[u] = (double)fm[u < n / 2 ? u : n - 1 - u]; }
+static void composite_taps(const float *fm, double *g /* [179] */) {
+  for (int u = 0; u < 179; u++) {
+    double a = 0.0;
+    for (int i = 0; i < 90; i++) {
+      const int j = u - i;
+      if (j < 0 || j >= 90) continue;
+      a += (double)fm[i < 45 ? i : 89 - i] * (double)fm[j < 45 ? j : 89 - j];
+    }
+    g[u] = a;
+  }
+}
+static double stage_d_error_lsb(const float *fm, int n, int qf, float coef) {
+  double h[256];
+  fm_full(fm, n, h);
+  return fixed_point_error(h, n, qf, (double)coef).rms;
+}
+#define FMD_STAGE_D_MAX_LSB 0.10
 
 static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
   if (k->resample && k->mode == 1 && k->size == 128)       /* mono: one emit per four samples, or per pair (resample_mono_i8) */
@@ -354,20 +394,8 @@ static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
 static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
   if (k->size != 90) return -1;
   double g[179];
-  for (int u = 0; u < 179; u++) {
-    double a = 0.0;
-    for (int i = 0; i < 90; i++) {
-      const int j = u - i;
-      if (j < 0 || j >= 90) continue;
-      a += (double)t->fm[i < 45 ? i : 89 - i] * (double)t->fm[j < 45 ? j : 89 - j];
-    }
-    g[u] = a;
-  }
-  double mx = 0.0, sh2 = 0.0;
-  for (int u = 0; u < 179; u++) { mx = fmax(mx, fabs(g[u])); sh2 += g[u] * g[u]; }
-  if (!(mx > 0.0) || !isfinite(mx)) return -1;
-  int qf = 40;
-  while (qf > 0 && llround(mx * ldexp(1.0, qf)) > 8355711LL) qf--;
+  composite_taps(t->fm, g);
+  const int qf = taps_qf(g, 179);
   if (qf < 8) return -1;
   double sum_abs = 0.0;
   for (int u = 0; u < 179; u++) {
@@ -377,13 +405,8 @@ static int build_lr_composite(const fmd_taps *t, fmdk_params *k) {
     if (u < 90) k->gq[u] = (int32_t)E;
   }
   if (128.0 * sum_abs >= 4194304.0 - 65536.0) return -1;
-  /* error estimate in LSB: stage_d_error_lsb's three terms for 179 taps */
-  const double c0 = ldexp(1.0, 12 - qf);
-  const double dropped = c0 * ldexp(1.0, -24) * sqrt(2.0 * 179.0) * 74.0 * 74.0;
-  const double samples = ldexp(1.0, -21) / sqrt(3.0) * sqrt(sh2);
-  const double taps = sqrt(179.0) * ldexp(1.0, -(qf + 1)) / sqrt(3.0) * 1.8;
   /* (the decimating form's window holds every tap of every row; round 5's full-rate form lacked the last two in two of sixteen rows and carried a term for them) */
-  if (fabs((double)k->coef) * sqrt(dropped * dropped + samples * samples + taps * taps) > FMD_STAGE_D_MAX_LSB) return -1;
+  if (fixed_point_error(g, 179, qf, (double)k->coef).rms > FMD_STAGE_D_MAX_LSB) return -1;
   k->g_qf = qf;
   k->g_scale = (float)ldexp(1.0, 12 - qf);
   k->g_unit = (float)ldexp(1.0, -qf);
@@ -492,7 +515,7 @@ static void fill_params(fmd_batch *b) {
      * reference's ORDER of operations: that removes the order-of-summation part of the difference to the reference (what is left:
      * the window's samples are a few ulps off each, and roundings that fall differently because of it).  Only samples within
      * L K of the origin after that are recomputed from the IQ words.  L was measured like K (tools/fuzz_parity.py and the noise /
-     * hand-over tests with FMD_CARRIER_L2 in a tuning build, profiles/r04w_carrier_l2.txt). */
+     * hand-over tests with FMD_CARRIER_L2 in a tuning build, profiles/archive/r04w_carrier_l2.txt). */
     float L2 = FMD_CARRIER_L2_DEFAULT;
     const char *el = tuning_env("FMD_CARRIER_L2");
     if (el) L2 = (float)atof(el);
@@ -619,6 +642,47 @@ int fmd_config_family(const fmd_config *cfg, const fmd_taps *taps) {
   return rc ? rc : fam;
 }
 
+int fmd_config_error_estimate(const fmd_config *cfg, const fmd_taps *taps, fmd_error_estimate *out) {
+  if (!out) return fail(FMD_E_ARG, "out is NULL");
+  memset(out, 0, sizeof(*out));
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  fmd_batch *b = (fmd_batch *)calloc(1, sizeof(*b));
+  if (!b) return fail(FMD_E_NOMEM, "out of host memory");
+  b->n_streams = 1;
+  rc = resolve_family(b, cfg, taps);
+  if (!rc) {
+    out->family = b->cfg.math;
+    out->limit_rms_lsb = (float)FMD_STAGE_D_MAX_LSB;
+    double h[256], g[179];
+    const double coef = (double)b->kp.coef;
+    stage_error e[2];
+    int n = 0;
+    if (cfg->rate_out2 > 0 && cfg->mode == 2 && cfg->size == 90) {
+      composite_taps(b->taps.fm, g);
+      fm_full(b->taps.fm, 90, h);
+      const int qg = taps_qf(g, 179), qh = taps_qf(h, 90);
+      if (qg >= 8 && qh >= 8) { e[0] = fixed_point_error(g, 179, qg, coef); e[1] = fixed_point_error(h, 90, qh, coef); n = 2; }
+    } else if (cfg->rate_out2 > 0 && cfg->mode == 1 && cfg->size == 128) {
+      fm_full(b->taps.fm, 128, h);
+      const int qh = taps_qf(h, 128);
+      if (qh >= 8) { e[0] = fixed_point_error(h, 128, qh, coef); n = 1; }
+    }
+    out->filters = n;
+    for (int i = 0; i < n; i++) {
+      out->f[i].taps = e[i].n;
+      out->f[i].qf = e[i].qf;
+      out->f[i].rms_lsb = (float)e[i].rms;
+      out->f[i].worst_samples_lsb = (float)e[i].worst_samples;
+      out->f[i].worst_taps_lsb = (float)e[i].worst_taps;
+      out->f[i].worst_dropped_lsb = (float)e[i].worst_dropped;
+      out->f[i].worst_lsb = (float)(e[i].worst_samples + e[i].worst_taps + e[i].worst_dropped);
+    }
+  }
+  free(b);
+  return rc;
+}
+
 int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *taps, int n_streams,
                      int device) {
   if (!out) return fail(FMD_E_ARG, "out is NULL");
@@ -671,6 +735,7 @@ static hipError_t batch_quiesce(fmd_batch *b) {
       (t = hipStreamSynchronize(b->last_stream)) != hipSuccess) e = t;
   if (b->copy_stream && (t = hipStreamSynchronize(b->copy_stream)) != hipSuccess) e = t;
   if (b->stream && (t = hipStreamSynchronize(b->stream)) != hipSuccess) e = t;
+  if (e == hipSuccess) b->launched = 0;        /* nothing of this batch is in flight: the next launch needs no hand-over, whatever stream it is on */
   return e;
 }
 
@@ -737,7 +802,7 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
    * workers (wavefronts) per CU; each chunk > 0 replays warm_tiles tiles first
    * (see the kernel), so keep chunks at least 4x longer than the replay.  (8x until round 3: a one-block launch of
    * 256 streams then ran as four chunks per stream = ONE wave per SIMD, which takes 7 us per tile with nobody to hide its
-   * latencies under - 0.094 ms; eight chunks of 4 + 1 tiles, two waves per SIMD: profiles/r03y_blocks_per_launch.txt) */
+   * latencies under - 0.094 ms; eight chunks of 4 + 1 tiles, two waves per SIMD: profiles/archive/r03y_blocks_per_launch.txt) */
   kp.n_streams = b->n_streams;
   kp.warm_tiles = fmdk_warm_tiles(&kp, b->cfg.math);
   kp.n_chunks = 1;
@@ -760,19 +825,29 @@ int fmd_batch_run_device_debug(fmd_batch *b, const void *d_iq, int n_blocks, voi
   /* The state is always ping-ponged (the kernel's in / out pointers never alias).  Launches on one
    * stream are ordered by the stream; when the stream changes between two launches an event makes
    * the new stream wait for the previous launch, whose output state this one reads. */
+  /* A caller's stream that is being captured into a hipGraph: the launch becomes a node of the graph.  The timing events have no meaning there (the launch
+   * carries none and fmd_batch_last_kernel_ms says so afterwards), and the event hand-over between streams would record an event of the batch on a stream
+   * outside the capture - which invalidates the capture: refused, with what to do instead. */
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+  const int capturing = cap != hipStreamCaptureStatusNone;
   if (b->launched && b->last_stream != st) {
+    if (capturing)
+      return fail(FMD_E_STATE, "the batch's previous launch ran on another stream: call fmd_batch_sync() before capturing this one into a graph (an event "
+                               "hand-over between streams cannot be recorded inside a capture)");
     HIP_TRY(hipEventRecord(b->ev_order, b->last_stream));
     HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
   }
   const int nxt = b->cur ^ 1;
+  const int with_events = !b->no_timing && !capturing;
   /* the timing events ride on the kernel's dispatch packet (fmdk_launch): no packets of their own */
   int e = fmdk_launch(&kp, b->cfg.math, b->n_streams, d_iq, d_pcm, d_lens, b->d_state[b->cur],
-                      b->d_state[nxt], dbg, st, b->no_timing ? NULL : (void *)b->ev0, b->no_timing ? NULL : (void *)b->ev1);
+                      b->d_state[nxt], dbg, st, with_events ? (void *)b->ev0 : NULL, with_events ? (void *)b->ev1 : NULL);
   if (e) return fail(FMD_E_HIP, "kernel launch failed: %s (%d)", hipGetErrorString((hipError_t)e), e);
   b->cur = nxt;
   b->last_stream = st;
   b->launched = 1;
-  b->timed = !b->no_timing;
+  b->timed = with_events;           /* (a captured launch has no events: fmd_batch_last_kernel_ms then reports FMD_E_STATE instead of a stale time) */
   return FMD_OK;
 }
 
@@ -804,7 +879,7 @@ int fmd_batch_wait_stream(fmd_batch *b, void *producer_stream) {
 
 int fmd_batch_last_kernel_ms(fmd_batch *b, float *ms) {
   if (!b || !ms) return fail(FMD_E_ARG, "NULL argument");
-  if (!b->timed) return fail(FMD_E_STATE, "no kernel has been launched yet");
+  if (!b->timed) return fail(FMD_E_STATE, "the most recent launch carries no timing events (none launched yet, timing off, or captured into a graph)");
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
   return FMD_OK;

@@ -3,7 +3,7 @@
 Every batch launches on its own HIP stream, so a process that demodulates two station groups (say a 300 k and a
 240 k batch, or a stereo and a mono one) has waves of two different fused kernels resident on the same SIMDs.
 Round 3 found the fast families computing wrong PCM beside a neighbour wave that issues 128-bit-operand MFMAs
-(profiles/r03m_mfma_neighbour.txt) - and the default family issues exactly such an instruction itself
+(profiles/archive/r03m_mfma_neighbour.txt) - and the default family issues exactly such an instruction itself
 (v_mfma_i32_16x16x64_i8, 36 per tile).  This is the product's own way into that situation: nothing is
 synchronised between the two batches' launches, every launch of every stream is held against the oracle
 (the reference's arithmetic, src/rtl_fm_player.c:758-788; tolerance +-1 LSB, BASELINE.json).

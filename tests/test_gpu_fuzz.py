@@ -158,3 +158,36 @@ def test_rccl_counter_gather_runs_on_one_gpu(R):
     assert d["counters_gathered_over"] == "nccl" and d["n_gpus"] == 1
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["samples"] == 16 * 2 * 131072 * 4
     assert d["parity"]["max_abs_lsb"] <= 1
+
+
+@pytest.mark.parametrize("name,kw,volume", [
+    # the largest volumes at which the rms estimate of the fixed-point second stage still passes its gate (0.10 LSB: csrc/fmd_host.c, fixed_point_error)
+    ("stereo_300k", dict(rate_in=300000, rate_out2=48000, mode=2), 7.5), ("stereo_240k", dict(rate_in=240000, rate_out2=48000, mode=2), 3.8),
+    ("stereo_192k", dict(rate_in=192000, rate_out2=48000, mode=2), 3.8), ("mono_300k", dict(rate_in=300000, rate_out2=48000, mode=1), 8.8),
+    ("nfm_25k", dict(rate_in=25000, rate_out2=12500, mode=1), 1.14),
+])
+def test_second_stage_at_the_gate_volumes(R, name, kw, volume):
+    """the +-1 LSB contract of the matrix-pipe second stage is gated by an rms ESTIMATE; pin the configurations that sit right under the gate.
+    32 streams x 8 blocks each of noise and of a low-amplitude carrier (where the second stage's own error is the largest share of a PCM step),
+    FMD_MATH_FAST_MFMA_F against the oracle: 1 LSB at most."""
+    import torch
+    from oracle import OracleStream, lcg_bytes
+    BL, NB, NS = 262144, 8, 32
+    cfg = R.wbfm_config(block_len=BL, math=R.MATH_FAST, volume=volume, **kw)
+    est = R.config_error_estimate(cfg)
+    assert est["family"] == R.MATH_FAST_MFMA_F and 0.09 < max(f["rms_lsb"] for f in est["filters"]) <= 0.10, est
+    rng = np.random.default_rng(1234)
+    noise = np.stack([lcg_bytes(NB * BL, 900 + s)[0] for s in range(NS // 2)])
+    # low-amplitude input: a few LSB of noise around the centre
+    quiet = (127.5 + rng.normal(0.0, 2.0, (NS - NS // 2, NB * BL))).round().clip(0, 255).astype(np.uint8)
+    iq = np.concatenate([noise, quiet]).reshape(NS, NB, BL)
+    b = R.BatchDemod(cfg, NS)
+    assert b.math == R.MATH_FAST_MFMA_F
+    got, lens = b.run_host_concat(iq, NB)
+    worst = 0
+    for s in range(NS):
+        want, wl = OracleStream(volume=volume, **kw).run(iq[s].reshape(-1), BL)
+        assert np.array_equal(lens[s], wl)
+        worst = max(worst, int(np.abs(got[s].astype(np.int32) - want.astype(np.int32)).max()))
+    b.close()
+    assert worst <= 1, (name, volume, worst)

@@ -1,7 +1,7 @@
 """The +-1 LSB families beside a neighbour wave that issues double-rate MFMAs on every SIMD.
 
-Round 3 measured wrong PCM here (every stream of every launch under v_mfma_f32_16x16x32_bf16, profiles/r03m_*);
-round 4 found the one instruction form behind it and took it out of the kernels (profiles/r04_pk_opsel_hazard.md,
+Round 3 measured wrong PCM here (every stream of every launch under v_mfma_f32_16x16x32_bf16, profiles/archive/r03m_*);
+round 4 found the one instruction form behind it and took it out of the kernels (profiles/archive/r04_pk_opsel_hazard.md,
 tools/isa_lint.py).  This is the short form of tools/diag/coburst.py: 256 streams fed the same IQ, launches made while
 tools/diag/coburst.hip keeps one MFMA-only wave per SIMD busy on its own stream; every stream of every launch must equal
 the PCM of a launch made alone, and that PCM is held against the oracle (the reference's arithmetic,

@@ -488,6 +488,9 @@ def test_launches_captured_in_a_hip_graph(R, math):
     with torch.cuda.graph(g, stream=st):
         for iq, pcm, lens in bufs:
             b.run_device(iq, 1, pcm, lens, hip_stream=st.cuda_stream)
+    # a captured launch carries no timing events: asking for its time is a call-sequence error, not a stale number
+    with pytest.raises(R.FmdError):
+        b.last_kernel_ms()
     b.reset()
     out = [[] for _ in range(S)]
     for k in range(0, 8, 2):
@@ -505,6 +508,22 @@ def test_launches_captured_in_a_hip_graph(R, math):
         assert got.size == want.size
         d = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
         assert d <= (0 if math == "exact" else 1), (s, d)
+    # ... and a capture that would need the batch's event hand-over between streams (its previous launch sits on another stream, not yet
+    # synchronised) is refused before anything is recorded into it; after fmd_batch_sync() the same capture goes through
+    iq, pcm, lens = bufs[0]
+    b.run_device(iq, 1, pcm, lens)                     # on the batch's own stream
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=st):
+        with pytest.raises(R.FmdError):
+            b.run_device(iq, 1, pcm, lens, hip_stream=st.cuda_stream)
+        lens.zero_()                                   # (something for the capture to hold)
+    b.sync()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, stream=st):
+        b.run_device(iq, 1, pcm, lens, hip_stream=st.cuda_stream)
+        b.run_device(iq, 1, pcm, lens, hip_stream=st.cuda_stream)
+    g3.replay()
+    torch.cuda.synchronize()
     b.close()
 
 

@@ -1,5 +1,5 @@
 """The kernels must not contain the packed-fp32 instruction form that computes wrong results beside double-rate MFMAs
-(profiles/r04_pk_opsel_hazard.md): tools/isa_lint.py over the device assembly of the three kernel translation units.
+(profiles/archive/r04_pk_opsel_hazard.md): tools/isa_lint.py over the device assembly of the three kernel translation units.
 hipcc cross-compiles without a GPU, so this runs in the CPU suite."""
 import os
 import sys
@@ -54,9 +54,19 @@ def test_kernels_have_no_scratch_and_no_spills(kind):
     bad = [(n, sc, sp) for n, sc, sp in zip(names, scratch, spills) if sp]
     assert not bad, "kernels with VGPR spills: %s" % bad
     assert len(sspills) == len(names)
-    # a private segment may exist (SGPR spill slots hipcc then served from VGPR lanes) - but nothing may ACCESS it
+    # a private segment may exist (SGPR spill slots hipcc then served from VGPR lanes: 20 - 36 bytes today) - but nothing may ACCESS it, it stays
+    # a few bytes, and the SGPR spill counts stay in the range they have today (a spill served through another addressing form would
+    # otherwise pass silently)
     body = text[:text.index("amdhsa.kernels:")]
     assert not re.findall(r"^\s+scratch_(?:load|store)", body, re.M), "scratch access in the device code"
+    big = [(n, sc) for n, sc in zip(names, scratch) if sc > isa_lint.PRIVATE_SEGMENT_MAX]
+    assert not big, "private segments beyond %d bytes: %s" % (isa_lint.PRIVATE_SEGMENT_MAX, big)
+    many = [(n, ss) for n, ss in zip(names, sspills) if ss > isa_lint.SGPR_SPILL_MAX]
+    assert not many, "SGPR spill counts beyond %d: %s" % (isa_lint.SGPR_SPILL_MAX, many)
+    # the shipped default kernels (every stage on the matrix pipe: MX = 2, no debug taps) reserve no private segment at all
+    for n, sc in zip(names, scratch):
+        if re.search(r"fmd_fused_kernelILb0ELi[12]ELi(45|64)ELi2ELb0E", n):
+            assert sc == 0, (n, sc)
 
 
 def test_the_built_library_is_what_gets_linted():
@@ -68,8 +78,18 @@ def test_the_built_library_is_what_gets_linted():
         import rtl_fm_player_amd as R
         R.build_library()
     n_pk, found, kernels = isa_lint.lint_so(so)
-    assert n_pk > 1500 and len(kernels) >= 20, (n_pk, len(kernels))
+    assert n_pk > 1500 and len(kernels) >= 16, (n_pk, len(kernels))
     errors = [f for f in found if f[1] == "error"]
     assert not errors, errors[:3]
     assert not [k for k in kernels if k[2] or k[3]], [k for k in kernels if k[2] or k[3]]     # spilled VGPRs / a scratch access
+    assert not [k for k in kernels if k[1] > isa_lint.PRIVATE_SEGMENT_MAX or k[4] > isa_lint.SGPR_SPILL_MAX], kernels
     assert any("fmd_fused_kernel" in k[0] for k in kernels)
+
+
+def test_a_missing_lint_tool_is_not_a_finding(tmp_path, monkeypatch):
+    """"could not look" (no llvm-objdump --offloading under $ROCM) is reported as such - exit code 3, which csrc/Makefile turns into a
+    refusal or, with ISA_LINT_OPTIONAL=1, a warning - not as a forbidden instruction."""
+    monkeypatch.setattr(isa_lint, "LLVM_BIN", str(tmp_path))
+    with pytest.raises(isa_lint.ToolUnavailable):
+        isa_lint.so_disassembly(os.path.join(ROOT, "rtl_fm_player_amd", "libfmdemod_mi355x.so"))
+    assert isa_lint.main(["--so", os.path.join(ROOT, "rtl_fm_player_amd", "libfmdemod_mi355x.so")]) == 3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage: tools/ablate.sh <mask> [waves per SIMD]  -> .ablate/lib_ab<mask>.so with the stages in <mask> compiled out
-# (FMD_ABLATE in csrc/fmd_kernels.inc: 1 A, 2 B, 4 C, 8 D, 16 F).  Timing builds only: results are garbage.
+# (FMD_ABLATE in csrc/fmd_kernels.inc: 1 A, 2 B, 4 C, 8 D, 16 F, +32: the stages behind a compiled-out B or C keep live operands).  Timing builds only: results are garbage.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 M=$1; W=${2:-3}

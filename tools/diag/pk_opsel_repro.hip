@@ -3,7 +3,7 @@
 // d.lo = a.lo + b.hi - gets d.lo of lanes 48-63 WRONG (computed as if b.hi were 0) while another wave of the same SIMD
 // issues v_mfma_f32_16x16x32_bf16 back to back.  The same sum with the swapped operand first (op_sel:[1,0]
 // op_sel_hi:[0,1], operands exchanged) or as two v_add_f32 is always right.  Found in round 4 of this repository through the
-// fused FM-demodulation kernels (profiles/r04_pk_opsel_hazard.md; the cut-out of their stage A is tools/diag/repro/).
+// fused FM-demodulation kernels (profiles/archive/r04_pk_opsel_hazard.md; the cut-out of their stage A is tools/diag/repro/).
 //   hipcc --offload-arch=gfx950 -O3 -o pk_opsel_repro pk_opsel_repro.hip && ./pk_opsel_repro [launches] [iterations]
 // Every victim wave checks itself: the result of the form under test against the same sum from two plain v_add_f32.
 #include <hip/hip_runtime.h>

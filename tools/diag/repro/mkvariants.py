@@ -92,7 +92,7 @@ def at_line(text, pat, before=None, after=None, others_before=None):
             if k == i and after: o.append("\t" + after)
         return o
     return body_edit(text, f)
-FAIL = "v_pk_add_f32 v[44:45], v[38:39], v[28:29]"      # y2[2] of the base build: the value that goes wrong (profiles/r04a)
+FAIL = "v_pk_add_f32 v[44:45], v[38:39], v[28:29]"      # y2[2] of the base build: the value that goes wrong (profiles/archive/r04a)
 assert FAIL in base
 def swap_wait(text):
     def f(ls):

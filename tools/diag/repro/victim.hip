@@ -1,4 +1,4 @@
-// Victim of the neighbour experiment (profiles/r03m_*), cut out of the product: stage A of the
+// Victim of the neighbour experiment (profiles/archive/r03m_*), cut out of the product: stage A of the
 // vector-ALU fast family (decimate8_own of csrc/fmd_kernels.inc: the lane's own eight IQ words, SDWA byte conversions,
 // v_pk_fma_f32 with scalar taps, the rot90 join as v_pk_add_f32 with operand modifiers, DPP hand-over of three outputs)
 // and nothing else.  Every wave of the grid runs the same tiles of the same IQ bytes, so every wave's outputs must equal

@@ -5,10 +5,10 @@
     time at the cap   = (bytes + instruction terms) / (CAP_W - BASE_W)        (the kernel is energy-bound: DESIGN.md section 5)
 
 with the per-launch instruction counts the PMC passes measured (SQ_INSTS_VALU - of which SQ_INSTS_MFMA -, SQ_INSTS_LDS, SQ_INSTS_SALU) and the
-list prices of tools/ubench/power_price.hip (profiles/r18_power_price.txt, r21_power_price_lds.txt).  Prints predicted against measured kernel time.
-    python tools/energy_model.py profiles/r30q_stereo_summary.json [more summaries ...]
+list prices of tools/ubench/power_price.hip (profiles/archive/r18_power_price.txt, r21_power_price_lds.txt).  Prints predicted against measured kernel time.
+    python tools/energy_model.py profiles/archive/r30q_stereo_summary.json [more summaries ...]
 Constants: BASE_W 367 (every SIMD on s_nop), CAP_W = what the package was measured at under that workload (1 379 stereo, 1 400 mono / narrow FM),
-NJ_PER_BYTE 0.124 (device-to-device copy, profiles/r33_stream_power.txt), list prices in nJ per wave instruction: MFMA i8 3.8, vector 0.65 (the kernels'
+NJ_PER_BYTE 0.124 (device-to-device copy, profiles/archive/r33_stream_power.txt), list prices in nJ per wave instruction: MFMA i8 3.8, vector 0.65 (the kernels'
 mix of plain 0.5 - 0.63 and packed 1.56), LDS 2.1, scalar 0.05; TOGGLE 1.6 = real operands over the micro-benchmark's constants: ONE factor, chosen so that
 the stereo kernel closes (rounds 4 / 5 stereo summaries: 0.98 - 1.02 of the measured time; mono / narrow FM are over-predicted by 10 - 12 %: DESIGN.md says why)."""
 import json, sys

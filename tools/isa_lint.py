@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ISA lint of the gfx950 kernels: no packed-fp32 instruction may pick DIFFERENT halves of its register sources for the low lane.
 
-Finding of round 4 (tools/diag/repro, profiles/r04_pk_opsel_hazard.md): a VOP3P fp32 instruction whose op_sel differs between its
+Finding of round 4 (tools/diag/repro, profiles/archive/r04_pk_opsel_hazard.md): a VOP3P fp32 instruction whose op_sel differs between its
 sources - e.g. `v_pk_add_f32 d, a, b op_sel:[0,1]`: low lane = a.lo + b.hi - computes its low-lane result for lanes 48-63 from a ZERO
 instead of the high half while another wave of the SIMD issues 128-bit-operand MFMAs (v_mfma_f32_16x16x32_bf16 and friends).  Uniform
 selections (op_sel all 0 or all 1 over the register sources), op_sel_hi in any combination, neg / neg_hi and scalar sources were clean
@@ -23,13 +23,22 @@ PK = re.compile(r"^\s+(v_pk_(?:fma|mul|add)_f32|v_pk_mov_b32)\s+(.*)$")
 
 def device_asm(kind, extra=()):
     out = "/tmp/fmd_lint_%s.s" % kind
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
                     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-fno-slp-vectorize", "-S", "--cuda-device-only",
                     "-o", out, os.path.join(CSRC, "fmd_kernels_%s.hip" % kind)] + list(extra), check=True, stderr=subprocess.DEVNULL)
     return out
 
 
-LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+ROCM = os.environ.get("ROCM") or os.environ.get("ROCM_PATH") or "/opt/rocm"     # (csrc/Makefile passes its own ROCM)
+LLVM_BIN = os.path.join(ROCM, "lib", "llvm", "bin")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+PRIVATE_SEGMENT_MAX = 64       # bytes a kernel's private segment may reserve WITHOUT touching it (SGPR spill slots that went to VGPR lanes: 20 - 36 seen)
+SGPR_SPILL_MAX = 200           # per kernel (118 - 160 in the stereo kernels at the register limit, 26 - 46 in the mono ones): beyond that something changed
+
+
+class ToolUnavailable(RuntimeError):
+    """llvm-objdump / llvm-readelf missing or without --offloading support: the lint could not LOOK - not the same as having found something."""
+
 
 
 def so_disassembly(so_path):
@@ -40,7 +49,12 @@ def so_disassembly(so_path):
     try:
         local = os.path.join(tmp, "lib.so")
         shutil.copy(so_path, local)
-        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for tool in ("llvm-objdump", "llvm-readelf"):
+            if not os.path.exists(os.path.join(LLVM_BIN, tool)):
+                raise ToolUnavailable("%s not found under %s (set ROCM=...)" % (tool, LLVM_BIN))
+        r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise ToolUnavailable("llvm-objdump --offloading failed: %s" % r.stderr.strip()[-200:])
         objs = sorted(glob.glob(local + ".*gfx950*"))
         if not objs:
             raise RuntimeError("no gfx950 code object in %s" % so_path)
@@ -51,7 +65,8 @@ def so_disassembly(so_path):
             names = re.findall(r"\.name:\s+(\S+)", notes)
             scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
             spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
-            kernels += list(zip(names, scratch, spills))
+            sspills = [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", notes)]
+            kernels += list(zip(names, scratch, spills, sspills))
         return "\n".join(text), kernels
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -77,7 +92,7 @@ def kernels_touching_scratch(text):
 def lint_so(so_path):
     text, kernels = so_disassembly(so_path)
     touching = kernels_touching_scratch(text)
-    kernels = [(n, sc, sp, n in touching) for n, sc, sp in kernels]
+    kernels = [(n, sc, sp, n in touching, ss) for n, sc, sp, ss in kernels]
     n_pk, found = 0, []
     for no, line in enumerate(text.splitlines(), 1):
         line = line.split("//")[0]
@@ -100,7 +115,7 @@ def split_operands(s):
 
 def check_line(line):
     """(level, why) or None.  level "error": the signature that computed wrong results in tools/diag/repro (low lane = LOW half of
-    one vector register pair with the HIGH half of a later, different pair: forms 0, 1, 6, 7, 11 of profiles/r04_pk_opsel_hazard.md);
+    one vector register pair with the HIGH half of a later, different pair: forms 0, 1, 6, 7, 11 of profiles/archive/r04_pk_opsel_hazard.md);
     "warn": other mixed selections, which were clean in every run (forms 8, 13 - 15: a high half first; horizontal operations on one
     register pair: 17, 18) and are only counted."""
     m = PK.match(line)
@@ -137,15 +152,22 @@ def main(kinds):
         kinds = ["so:" + k for k in kinds[1:]]
     for kind in kinds:
         if kind.startswith("so:"):
-            n_pk, found, kernels = lint_so(kind[3:])
-            bad = [k for k in kernels if k[2] or k[3]]
+            try:
+                n_pk, found, kernels = lint_so(kind[3:])
+            except ToolUnavailable as e:
+                # the lint could not look: say so and leave the decision to the caller (exit code 3; csrc/Makefile refuses unless ISA_LINT_OPTIONAL=1)
+                print("%s: lint tool unavailable: %s" % (kind, e))
+                return 3
+            # a spilled VGPR, a scratch access, a private segment beyond the few bytes of untouched SGPR spill slots, or an SGPR spill count out of range
+            bad = [k for k in kernels if k[2] or k[3] or k[1] > PRIVATE_SEGMENT_MAX or k[4] > SGPR_SPILL_MAX]
             if n_pk < 500 or not kernels:
                 print("%s: %d packed-fp32 instructions in %d kernels: not the library this lint is for" % (kind, n_pk, len(kernels)))
                 rc |= 1
-            for name, sc, sp, touch in bad:
-                print("   error: kernel %s: %d spilled VGPRs, %s its %d bytes of scratch" % (name, sp, "accesses" if touch else "does not access", sc))
-            for name, sc, sp, touch in kernels:
-                if sc and not sp and not touch:
+            for name, sc, sp, touch, ss in bad:
+                print("   error: kernel %s: %d spilled VGPRs, %d spilled SGPRs (limit %d), %s its %d bytes of scratch (limit untouched: %d)" %
+                      (name, sp, ss, SGPR_SPILL_MAX, "accesses" if touch else "does not access", sc, PRIVATE_SEGMENT_MAX))
+            for name, sc, sp, touch, ss in kernels:
+                if sc and not sp and not touch and sc <= PRIVATE_SEGMENT_MAX:
                     print("   note: kernel %s has a private segment of %d bytes it never accesses (SGPR spill slots that went to VGPR lanes)" % (name, sc))
             rc |= bool(bad)
         else:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: what MOVING bytes costs.  A device-to-device copy and a read-only reduction of 1 GiB of random bytes, each looped for ~3 s with the package
 power and shader clock sampled from hwmon beside it (bench.PowerWatch): GB/s, W, MHz, and nJ per byte moved above the 367 W the part draws with every
-SIMD on s_nop (profiles/r18_power_price.txt).  The fused kernel's own stream (stage A alone, tools/energy_ablate.sh mask 30) sits next to these.
+SIMD on s_nop (profiles/archive/r18_power_price.txt).  The fused kernel's own stream (stage A alone, tools/energy_ablate.sh mask 30) sits next to these.
    python tools/stream_power.py"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
