@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--mode", default="stereo", choices=["stereo", "mono", "nfm"])
     ap.add_argument("--data", default="fm")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--volume", type=float, default=0.4)
     a = ap.parse_args()
     import torch
     import rtl_fm_player_amd as R
@@ -29,7 +30,7 @@ def main():
     dev = torch.device("cuda:0")
     fam = {"fast": R.MATH_FAST, "exact": R.MATH_EXACT, "fast-valu": R.MATH_FAST_VALU, "fast-mfma": R.MATH_FAST_MFMA,
            "fast-mfma-f": R.MATH_FAST_MFMA_F}[a.math]
-    cfg = R.wbfm_config(block_len=BL, math=fam,
+    cfg = R.wbfm_config(block_len=BL, math=fam, volume=a.volume,
                         **(dict(rate_in=25000, rate_out2=12500, mode=1) if a.mode == "nfm" else
                            dict(rate_in=300000, rate_out2=48000, mode=2 if a.mode == "stereo" else 1)))
     b = R.BatchDemod(cfg, a.streams, device=0)

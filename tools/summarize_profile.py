@@ -53,6 +53,9 @@ for f in find("trace/**/*kernel_trace.csv"):
         r0 = next(r for r in csv.DictReader(open(f)) if "fmd_" in r["Kernel_Name"])
         out["kernel_resources"] = {k: r0.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                                            "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+        # rocprofv3's VGPR_Count is the ARCH-VGPR half of gfx950's unified register file as the trace reports it (128 for a kernel whose code object says
+        # .vgpr_count 229 - 256 with no AGPRs in use): the code object's own figure is what the occupancy follows (label it)
+        out["kernel_resources"]["note"] = "VGPR_Count as rocprofv3 reports it; the code object's .vgpr_count (tools/isa_report.sh) is the allocation: 229 stereo / 168 mono for FMD_MATH_FAST_MFMA_F"
 
 
 def pmc(dirname):
