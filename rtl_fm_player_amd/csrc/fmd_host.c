@@ -188,6 +188,7 @@ struct fmd_batch {
   int time_split;              /* fmd_batch_set_time_split: 0 default, > 0 workers per CU to cut for, < 0 never split */
   /* staging for the host-buffer path, grown on demand */
   void *d_iq, *d_pcm, *d_lens;
+  void *d_dec_tables;          /* FMD_MATH_FAST_MFMA_F: the phase tables of the decimating second stage (build_dec_tables), NULL otherwise */
   size_t cap_blocks;
   /* ingest */
   struct fmd_ingest **ingest;  /* [n_streams], NULL when unbound */
@@ -630,6 +631,35 @@ static int resolve_family(fmd_batch *b, const fmd_config *cfg, const fmd_taps *t
   return FMD_OK;
 }
 
+/* The tap tables of the decimating second stage (csrc/stage_d.inc), as the kernel reads them: for byte phase r = 0 .. 15 and limb l = 0 .. 2, byte y of the
+ * table = limb l of T[Y0 - r - y] (zero outside the filter), T = round(h 2^qf) in three balanced int8 limbs, Y0 = P - 1 + K0.  Stereo: the composite filter
+ * (179 taps, gq, K0 180, 416 bytes per table) and behind it fm (90 taps, K0 92, 288 bytes); 128-tap mono: fm (K0 128, 368 bytes).  Returns malloc'd bytes. */
+static uint8_t *build_dec_tables(const fmd_batch *b, size_t *bytes) {
+  const fmdk_params *k = &b->kp;
+  const int stereo = b->cfg.mode == 2, P = k->dec_p;
+  const int fn = stereo ? FMDK_DF_N : FMDK_DM_N, ntaps = stereo ? 90 : 128, k0f = stereo ? FMDK_DEC_K0F : FMDK_DEC_K0M;
+  const size_t gbytes = stereo ? (size_t)16 * 3 * FMDK_DG_N : 0, fbytes = (size_t)16 * 3 * (size_t)fn;
+  uint8_t *t = (uint8_t *)calloc(1, gbytes + fbytes);
+  if (!t) return NULL;
+  for (int r = 0; r < 16; r++)
+    for (int l = 0; l < 3; l++) {
+      if (stereo)
+        for (int y = 0; y < FMDK_DG_N; y++) {
+          const int u = P - 1 + FMDK_DEC_K0G - r - y;
+          if (u >= 0 && u < 179) t[((size_t)r * 3 + l) * FMDK_DG_N + y] = (uint8_t)((((uint32_t)k->gq[u < 90 ? u : 178 - u] + 0x808080u) ^ 0x808080u) >> (8 * (2 - l)));
+        }
+      for (int y = 0; y < fn; y++) {
+        const int u = P - 1 + k0f - r - y;
+        if (u >= 0 && u < ntaps) {
+          const int E = (int)rintf(ldexpf(b->taps.fm[u < ntaps / 2 ? u : ntaps - 1 - u], k->ci_qf[0]));     /* (exact: |E| < 2^23) */
+          t[gbytes + ((size_t)r * 3 + l) * (size_t)fn + y] = (uint8_t)((((uint32_t)E + 0x808080u) ^ 0x808080u) >> (8 * (2 - l)));
+        }
+      }
+    }
+  *bytes = gbytes + fbytes;
+  return t;
+}
+
 int fmd_config_family(const fmd_config *cfg, const fmd_taps *taps) {
   int rc = check_config(cfg);
   if (rc) return rc;
@@ -716,6 +746,16 @@ int fmd_batch_create(fmd_batch **out, const fmd_config *cfg, const fmd_taps *tap
     fmd_batch_destroy(b);
     return rc;
   }
+  if (b->cfg.math == FMD_MATH_FAST_MFMA_F && b->kp.dec_p > 0) {
+    size_t nb = 0;
+    uint8_t *t = build_dec_tables(b, &nb);
+    if (!t) { fmd_batch_destroy(b); return fail(FMD_E_NOMEM, "out of host memory"); }
+    e = hipMalloc(&b->d_dec_tables, nb);
+    if (e == hipSuccess) e = hipMemcpy(b->d_dec_tables, t, nb, hipMemcpyHostToDevice);
+    free(t);
+    if (e != hipSuccess) { rc = fail(FMD_E_HIP, "device setup failed: %s", hipGetErrorString(e)); fmd_batch_destroy(b); return rc; }
+    b->kp.dec_tables = b->d_dec_tables;
+  }
   {
     hipDeviceProp_t prop;
     b->n_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -750,6 +790,7 @@ void fmd_batch_destroy(fmd_batch *b) {
   if (b->ingest)
     for (int i = 0; i < b->n_streams; i++)
       if (b->ingest[i]) ingest_detach(b->ingest[i]);
+  if (b->d_dec_tables) hipFree(b->d_dec_tables);
   if (b->d_state[0]) hipFree(b->d_state[0]);
   if (b->d_state[1]) hipFree(b->d_state[1]);
   if (b->d_iq) hipFree(b->d_iq);

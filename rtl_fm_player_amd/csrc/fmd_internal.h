@@ -16,6 +16,12 @@ extern "C" {
 
 #define FMDK_TILE 512         /* rate_in samples per tile: 64 lanes x 8 outputs           */
 #define FMDK_WAVES 4          /* workers (wavefronts) per workgroup                       */
+#define FMDK_DG_N 416         /* bytes per (byte phase, limb) of the decimating second stage's tap tables: composite L+R filter, */
+#define FMDK_DF_N 288         /* ... fm (90 taps), */
+#define FMDK_DM_N 368         /* ... fm (128 taps, mono) */
+#define FMDK_DEC_K0G 180      /* the window's first sample before the tile's first, per filter (resample_tile_dec / resample_mono_dec) */
+#define FMDK_DEC_K0F 92
+#define FMDK_DEC_K0M 128
 #ifndef FMDK_FRAME_CAP
 #define FMDK_FRAME_CAP 512    /* pending resampler outputs (floats) per worker before a flush */
 #endif
@@ -87,6 +93,9 @@ typedef struct fmdk_params {
   int32_t g_qf;
   float g_scale, g_unit;
   int32_t dec_p;                 /* FMD_MATH_FAST_MFMA_F: 16 rate_out / rate_out2 = samples per sixteen frames (a multiple of four in 64 .. 100), 0: the family does not apply (resample_tile_dec) */
+  const void *dec_tables;        /* ... device memory, made once per batch by the host (fmd_host.c, build_dec_tables): the sixteen byte phases of the reversed, zero-padded
+                                    limb tables the decimating second stage reads - stereo: 16 x 3 x FMDK_DG_N bytes of the composite filter, then 16 x 3 x FMDK_DF_N of
+                                    fm; 128-tap mono: 16 x 3 x FMDK_DM_N of fm.  The kernel's prologue copies them into LDS (one 16-byte word per thread and step) */
   int32_t dec_wide;              /* ... mono: more than eight groups of sixteen frames per tile (rate_out < 4 rate_out2): a column per group (resample_mono_dec) */
   int32_t pilot_pairs8;          /* matrix-pipe stage C: the pilot filter's class-3 limb pairs too (volume >= 1: the carrier's accuracy in LSB scales with it) */
   float org_thr, org_thr15;      /* (and 1.5 x it: the lane-level pre-test on max(|cross|, |dot|)) */
