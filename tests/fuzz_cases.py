@@ -38,6 +38,30 @@ def iter_cases(cases, seed, volumes=None):
         yield dict(case=case, kw=kw, block_len=block_len, nb=nb, launches=launches, ns=ns, seed0=1000 + case * 7)
 
 
+def iter_cases_f(cases, seed):
+    """Round 6: configurations FMD_MATH_FAST_MFMA_F runs (the draw of iter_cases reaches them twice in 400 cases) - 90-tap stereo at 300 k / 240 k / 192 k -> 48 k
+    and 128-tap mono at rates whose sixteen frames are a whole number of samples, whole tiles, volumes up to the error estimate's gate, everything else
+    random (de-emphasis, tau, offset tuning, blocks, launches, streams)."""
+    rng = random.Random(seed * 7919 + 17)
+    stereo = [(300000, 48000, 7.5), (240000, 48000, 3.8), (192000, 48000, 3.8)]
+    mono = [(300000, 48000, 8.8), (240000, 48000, 4.5), (192000, 48000, 4.5), (25000, 12500, 1.14), (96000, 32000, 1.0), (384000, 48000, 8.0), (96000, 48000, 2.0)]
+    for case in range(cases):
+        if rng.random() < 0.6:
+            rate_in, rate_out2, vmax = rng.choice(stereo)
+            mode, size = 2, 90
+        else:
+            rate_in, rate_out2, vmax = rng.choice(mono)
+            mode, size = 1, 128
+        volume = rng.choice([0.4, 0.4, 1.0, vmax, round(rng.uniform(0.1, vmax), 2)])
+        kw = dict(rate_in=rate_in, rate_out2=rate_out2, mode=mode, size=size, deemph=rng.random() < 0.8, offset_tuning=rng.random() < 0.2,
+                  volume=volume, tau=rng.choice([50e-6, 75e-6, 300e-6]))
+        block_len = rng.choice([8192, 16384, 32768, 65536, 262144, 262144])
+        launches = rng.choice([1, 1, 2, 3])
+        nb = launches * rng.randint(1, 4 if block_len >= 65536 else 12)
+        ns = rng.choice([1, 1, 2, 5])
+        yield dict(case=case, kw=kw, block_len=block_len, nb=nb, launches=launches, ns=ns, seed0=5000 + case * 11)
+
+
 def run_case(R, c, maths=None):
     """Returns a list of (math, stream, maxdiff) mismatches; [] when the case holds.  A configuration the
     library refuses (documented limits) or the oracle rejects counts as held."""

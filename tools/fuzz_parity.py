@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtl_fm_player_amd as R
-from fuzz_cases import iter_cases, run_case
+from fuzz_cases import iter_cases, iter_cases_f, run_case
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
-for c in iter_cases(cases, seed):
+# FUZZ_F=1: the draw biased to the configurations FMD_MATH_FAST_MFMA_F runs (tests/fuzz_cases.py, iter_cases_f)
+for c in (iter_cases_f(cases, seed) if os.environ.get("FUZZ_F") else iter_cases(cases, seed)):
     for math, s, d in run_case(R, c):
         bad += 1
         print("MISMATCH seed", seed, "case", c["case"], "math", math, "stream", s, "maxdiff", d, c["kw"],
