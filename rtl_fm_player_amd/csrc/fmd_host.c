@@ -134,7 +134,7 @@ static int check_config(const fmd_config *c) {
   if (c->size < 2 || c->size > 256 || (c->size & 1)) return fail(FMD_E_ARG, "lpr.size must be even, 2..256");
   if (c->block_len < 64 || (c->block_len & 15)) return fail(FMD_E_ARG, "block_len must be a multiple of 16, >= 64");
   if (c->math < FMD_MATH_EXACT || c->math > FMD_MATH_FAST_MFMA_F)
-    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA, _FAST_MFMA_C, _FAST_MFMA_D, _FAST_MFMA_E or _FAST_MFMA_F");
+    return fail(FMD_E_ARG, "math must be FMD_MATH_EXACT, _FAST, _FAST_VALU, _FAST_MFMA or _FAST_MFMA_F (4 - 6, the retired family names, mean _FAST)");
   /* the +-1 LSB kernels evaluate the de-emphasis blockwise with powers of lambda (scan weights, restarts from zero):
    * a contraction is assumed.  lambda outside (0, 1) - never produced by fmd_deemph_lambda - belongs to the exact kernels */
   if (c->math != FMD_MATH_EXACT && c->deemph && !(c->deemph_lambda > 0.f && c->deemph_lambda < 1.f))
@@ -286,12 +286,11 @@ static int build_ci_scales(const fmd_taps *t, int size, fmdk_params *k) {
   return 0;
 }
 
-/* Stage D on the matrix pipe as well (resample_tile_i8): the second-stage low-pass at every sample, the emit instants selected.
- * Needs what stage C needs (build_ci_scales) and: at most one emit among four consecutive samples (fast >= 4 slow), both
- * magic-number index forms, and {L+R, (L-R) x carrier} inside the limbs' range |x| < 8 for any discriminator output (|v| <= pi, and
- * what quirk Q1 can put in place of a sample: |om - os| <= 2 pi sum|fm| sum|f|) - true of any filter of the reference's design,
- * checked for a caller's. */
-/* The 128-tap mono path's one filter in the same fixed-point form (resample_mono_i8): T = round(fm 2^qf) in three balanced int8 limbs,
+/* (stage_d_on_matrix_pipe, below: the second stage on the matrix pipe needs what stage C needs - build_ci_scales - and: at most eight groups of sixteen
+ * frames per tile for stereo (rate_out >= 4 rate_out2; mono: sixteen, rate_out >= 2 rate_out2), both magic-number index forms, the error estimate under its
+ * limit, and (L-R) x carrier inside the limbs' range |x| < 8 for any discriminator output - |v| <= pi, and what quirk Q1 can put in place of a sample:
+ * |om - os| <= 2 pi sum|fm| sum|f| - true of any filter of the reference's design, checked for a caller's.) */
+/* The 128-tap mono path's one filter in the same fixed-point form (resample_mono_dec): T = round(fm 2^qf) in three balanced int8 limbs,
  * every weight class of the limb-pair sums inside +-2^22 for any samples. */
 static int build_ci_scales_mono(const fmd_taps *t, int size, fmdk_params *k) {
   if (size != 128) return -1;
@@ -376,7 +375,7 @@ static double stage_d_error_lsb(const float *fm, int n, int qf, float coef) {
 #define FMD_STAGE_D_MAX_LSB 0.10
 
 static int stage_d_on_matrix_pipe(const fmd_taps *t, const fmdk_params *k) {
-  if (k->resample && k->mode == 1 && k->size == 128)       /* mono: one emit per four samples, or per pair (resample_mono_i8) */
+  if (k->resample && k->mode == 1 && k->size == 128)       /* mono: rate_out >= 2 rate_out2 (at most sixteen groups of sixteen frames per tile) */
     return (long long)k->fast >= 2LL * k->slow && k->emit_magic && k->tf_magic &&
            stage_d_error_lsb(t->fm, 128, k->ci_qf[0], k->coef) <= FMD_STAGE_D_MAX_LSB;
   if (!(k->resample && k->mode == 2 && k->size == 90)) return 0;

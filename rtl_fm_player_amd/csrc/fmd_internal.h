@@ -72,23 +72,23 @@ typedef struct fmdk_params {
    * d = 4 s + g - r, zero outside 0..3 (fmd_host.c, build_a_tab). */
   int32_t a_tab[3 * 2 * 4 * 4];
   float a_bias_i, a_bias_q;          /* 2^-34 * sum of E over the window: the (u - 127.5) offset of the reference's table */
-  /* matrix-pipe form of stage C (FMD_MATH_FAST_MFMA_C, 90-tap stereo): taps of filter f (fm, fp, fs) as T = round(h 2^qf) in three
+  /* matrix-pipe form of stage C (FMD_MATH_FAST_MFMA_F, 90-tap stereo): taps of filter f (fm, fp, fs) as T = round(h 2^qf) in three
    * balanced int8 limbs (the kernel builds its byte tables from fm / fp / fs and qf), samples as round(v 2^20):
    * y = ci_scale[f] (A0 + A1 2^-8 + A2 2^-16 + A3 2^-24), ci_scale = 2^(32 - 20 - qf)  (fmd_kernels.inc, mpx_tile_i8) */
   int32_t ci_qf[3];
   float ci_scale[3];
-  /* matrix-pipe form of stage D (FMD_MATH_FAST_MFMA_D): stage C hands {L+R, (L-R) x carrier} over as round(x 2^20) in three int8 limbs,
+  /* ... whose second stage reads limbs: stage C hands (L-R) x carrier over as round(x 2^20) in three int8 limbs,
    * so its sums are put together at 2^20 times their value: ci_scale_q = 2^20 ci_scale, and the carrier's margin r^2 / K^2 - vs^2 is
-   * taken with the scaled vs: car_inv_k2_q = 2^40 / K^2 (fmd_kernels.inc, mpx_tile_i8<MFD>, resample_tile_i8) */
+   * taken with the scaled vs: car_inv_k2_q = 2^40 / K^2 (stage_c.inc, mpx_tile_i8; stage_d.inc, resample_tile_dec) */
   float ci_scale_q[3];
   float car_inv_k2_q;
   /* fast kernels: decimated samples with |I| + |Q| <= org_thr are redone in the reference's arithmetic (stage B).  1e-3 where it was
    * validated (narrow FM at the reference's default volume and everything with a larger PCM step per unit of discriminator error);
    * grows with coef x (largest tap of the filter behind the discriminator) beyond that: the phase error of such a sample is
    * (decimator difference) / magnitude and reaches the PCM through one tap */
-  /* FMD_MATH_FAST_MFMA_E: the L+R chain as one filter g = fm * fm (179 taps, symmetric) over the discriminator output: T_g = round(g 2^g_qf)
+  /* FMD_MATH_FAST_MFMA_F stereo: the L+R chain as one filter g = fm * fm (179 taps, symmetric) over the discriminator output: T_g = round(g 2^g_qf)
    * in three balanced int8 limbs, gq[u] = T_g[u] = T_g[178 - u] for u <= 89; y = g_scale (A0 + A1 2^-8 + A2 2^-16), g_scale = 2^(12 - g_qf);
-   * g_unit = 2^-g_qf turns a T_g into its tap for the cold paths (fmd_kernels.inc: mpx_tile_i8e, lr_head_fix) */
+   * g_unit = 2^-g_qf turns a T_g into its tap for the cold paths (cold_paths.inc: q1_patch_i8, lr_head_fix) */
   int32_t gq[90];
   int32_t g_qf;
   float g_scale, g_unit;

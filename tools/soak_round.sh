@@ -8,4 +8,4 @@ timeout 900 python tools/diag/determinism.py 7 2000 2 2>&1 | tail -2 > $O/determ
 timeout 900 python tools/diag/determinism.py 3 1000 2 2>&1 | tail -2 >> $O/determinism.txt
 timeout 900 python tools/diag/determinism.py 3 1000 1 2>&1 | tail -2 >> $O/determinism.txt
 timeout 900 python tools/diag/determinism.py 7 2000 1 2>&1 | tail -2 >> $O/determinism.txt
-awk '{m+=$NF; n+=$4} END {print "fuzz: cases", n, "mismatches", m}' $O/fuzz_soak.txt; awk '{m+=$NF; n+=$4} END {print "fuzz (the default family's configurations): cases", n, "mismatches", m}' $O/fuzz_f_soak.txt; cut -c1-250 $O/coburst_soak.txt; cat $O/determinism.txt
+awk '{m+=$NF; n+=$4} END {print "fuzz: cases", n, "mismatches", m}' $O/fuzz_soak.txt; awk '{m+=$NF; n+=$4} END {print "fuzz (the configurations of the default family): cases", n, "mismatches", m}' $O/fuzz_f_soak.txt; cut -c1-250 $O/coburst_soak.txt; cat $O/determinism.txt
