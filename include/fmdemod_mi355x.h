@@ -133,8 +133,7 @@ struct demod_state {      /* include/rtl_fm_player.h:127-175 */
  * Limits of this surface (it serves one dongle, like the program it drops into; many streams
  * belong on the batch API below):
  *   - the device side of a struct is found through a registry keyed by the struct's address
- *     (the reference struct has no spare field): at most 64 demod_state objects at a time, a
- *     65th aborts; fmd_demod_release (or deinit_lp_real_f32) frees a slot;
+ *     (the reference struct has no spare field); fmd_demod_release (or deinit_lp_real_f32) forgets a struct;
  *   - the arithmetic contract is read ONCE, at the first full_demod of the process, from the
  *     environment: FMD_MATH_FAST set -> +-1 LSB kernels, otherwise the bit-exact ones;
  *   - any HIP error is fatal (abort), because the signatures have no way to report it. */
@@ -148,6 +147,14 @@ void u8_f32(struct demod_state *d);                 /* :228 */
 void full_demod(struct demod_state *d);             /* :758 */
 /* Additive: release the device resources full_demod attached to *d. */
 void fmd_demod_release(struct demod_state *d);
+/* Additive: what the void calls above cannot say through their signatures.
+ *   fmd_dropin_set_math: the arithmetic family of the calls above (an fmd_config.math value), instead of the FMD_MATH_FAST environment variable; call it
+ *     before the first full_demod (a struct's batch is rebuilt when the family changes).
+ *   fmd_dropin_set_error_handler: by default a failure inside one of the calls above (no device, out of memory, a HIP error) prints a line and abort()s; with
+ *     a handler installed it is told (which call, fmd_last_error()'s text) and the call returns with result_len = 0. */
+int fmd_dropin_set_math(int math);
+typedef void (*fmd_dropin_error_fn)(const char *where, const char *message, void *ctx);
+void fmd_dropin_set_error_handler(fmd_dropin_error_fn fn, void *ctx);
 #endif /* FMD_NO_REFERENCE_TYPES */
 
 /* ------------------------------------------------------------------------

@@ -106,8 +106,8 @@ _lib = None
 
 _EXPORTS = [
     "init_u8_f32_table", "init_lp_f32", "init_lp_real_f32", "deinit_lp_real_f32", "demod_init",
-    "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release",
-    "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
+    "rotate_90_u8_f32", "u8_f32", "full_demod", "fmd_demod_release", "fmd_dropin_set_math", "fmd_dropin_set_error_handler",
+    "fmd_config_error_estimate", "fmd_design_taps", "fmd_deemph_lambda", "fmd_batch_create", "fmd_batch_destroy",
     "fmd_batch_pcm_stride", "fmd_batch_n_streams", "fmd_batch_math", "fmd_config_family", "fmd_batch_set_time_split", "fmd_batch_run_device", "fmd_batch_run_device_debug",
     "fmd_batch_sync", "fmd_batch_wait_stream", "fmd_batch_run_host", "fmd_batch_get_state", "fmd_batch_set_state",
     "fmd_batch_reset", "fmd_batch_last_kernel_ms", "fmd_batch_set_timing", "fmd_batch_kernel_name", "fmd_last_error",
@@ -119,6 +119,7 @@ _EXPORTS = [
 ]
 
 INGEST_CB = C.CFUNCTYPE(None, C.POINTER(C.c_ubyte), C.c_uint32, C.c_void_p)
+DROPIN_ERROR_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p, C.c_void_p)     # fmd_dropin_error_fn
 
 
 def exported_symbols():

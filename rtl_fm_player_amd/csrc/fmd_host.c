@@ -1017,36 +1017,66 @@ struct drop_in {
   size_t pin_pcm;     /* int16 capacity of pin->pcm */
 };
 
-#define DROP_IN_MAX 64
-static struct drop_in g_drop[DROP_IN_MAX];
+/* The registry: heap nodes behind a growing array of pointers (a node's address is stable for as long as its struct is registered; rounds 1 - 5 had 64
+ * fixed slots and aborted on the 65th struct). */
+static struct drop_in **g_drop;
+static int g_drop_n, g_drop_cap;
 static pthread_mutex_t g_drop_m = PTHREAD_MUTEX_INITIALIZER;
 
 static struct drop_in *drop_find(struct demod_state *d, int create) {
-  struct drop_in *hit = NULL, *empty = NULL;
+  struct drop_in *hit = NULL;
+  int empty = -1;
   pthread_mutex_lock(&g_drop_m);
-  for (int i = 0; i < DROP_IN_MAX; i++) {
-    if (g_drop[i].key == d) { hit = &g_drop[i]; break; }
-    if (!g_drop[i].key && !empty) empty = &g_drop[i];
+  for (int i = 0; i < g_drop_n; i++) {
+    if (g_drop[i] && g_drop[i]->key == d) { hit = g_drop[i]; break; }
+    if (!g_drop[i] && empty < 0) empty = i;
   }
-  if (!hit && create && empty) {
-    memset(empty, 0, sizeof(*empty));
-    empty->key = d;
-    hit = empty;
+  if (!hit && create) {
+    if (empty < 0 && g_drop_n == g_drop_cap) {
+      const int cap = g_drop_cap ? 2 * g_drop_cap : 16;
+      struct drop_in **g = (struct drop_in **)realloc(g_drop, (size_t)cap * sizeof(*g));
+      if (g) { g_drop = g; g_drop_cap = cap; }
+    }
+    if (empty < 0 && g_drop_n < g_drop_cap) { empty = g_drop_n++; g_drop[empty] = NULL; }
+    if (empty >= 0 && (hit = (struct drop_in *)calloc(1, sizeof(*hit)))) {
+      hit->key = d;
+      g_drop[empty] = hit;
+    }
   }
   pthread_mutex_unlock(&g_drop_m);
   return hit;
 }
+static void drop_forget(struct drop_in *di) {
+  pthread_mutex_lock(&g_drop_m);
+  for (int i = 0; i < g_drop_n; i++)
+    if (g_drop[i] == di) g_drop[i] = NULL;
+  pthread_mutex_unlock(&g_drop_m);
+  free(di);
+}
 
-/* FMD_MATH_FAST in the environment selects the +-1 LSB kernels for the reference-shaped calls;
- * read once (the first full_demod), not per block. */
-static int g_dropin_math = -1;
+/* The arithmetic family of the reference-shaped calls, whose signatures have no room for it: fmd_dropin_set_math() if the caller said so, else FMD_MATH_FAST in
+ * the environment selects the +-1 LSB kernels (read once, at the first full_demod), else the bit-exact ones. */
+static int g_dropin_math = -1, g_dropin_math_set = 0;
 static pthread_once_t g_dropin_once = PTHREAD_ONCE_INIT;
-static void dropin_read_env(void) { g_dropin_math = getenv("FMD_MATH_FAST") ? FMD_MATH_FAST : FMD_MATH_EXACT; }
+static void dropin_read_env(void) { if (!g_dropin_math_set) g_dropin_math = getenv("FMD_MATH_FAST") ? FMD_MATH_FAST : FMD_MATH_EXACT; }
+int fmd_dropin_set_math(int math) {
+  if (math < FMD_MATH_EXACT || math > FMD_MATH_FAST_MFMA_F) return fail(FMD_E_ARG, "fmd_dropin_set_math: not a math value");
+  g_dropin_math = math;
+  g_dropin_math_set = 1;
+  return FMD_OK;
+}
 
+/* What a failure inside a void reference-shaped call does: the caller's handler if one is installed (the call then returns with result_len = 0), else a line
+ * on stderr and abort() - a demodulator that silently stops producing audio is the worse failure for the program this drops into. */
+static fmd_dropin_error_fn g_dropin_err;
+static void *g_dropin_err_ctx;
+void fmd_dropin_set_error_handler(fmd_dropin_error_fn fn, void *ctx) { g_dropin_err = fn; g_dropin_err_ctx = ctx; }
 static void die(const char *what) {
+  if (g_dropin_err) { g_dropin_err(what, fmd_last_error(), g_dropin_err_ctx); return; }
   fprintf(stderr, "fmdemod_mi355x: %s: %s\n", what, fmd_last_error());
   abort();
 }
+#define DIE(d, what) do { die(what); if (d) (d)->result_len = 0; return; } while (0)
 
 void init_u8_f32_table(void) {}  /* the conversion is arithmetic on the device (exact, no table) */
 void init_lp_f32(void) {}        /* taps are designed per batch in fmd_design_taps              */
@@ -1105,9 +1135,7 @@ void fmd_demod_release(struct demod_state *d) {
   if (!di) return;
   fmd_batch_destroy(di->batch);
   if (di->pin) hipHostFree(di->pin);
-  pthread_mutex_lock(&g_drop_m);
-  memset(di, 0, sizeof(*di));
-  pthread_mutex_unlock(&g_drop_m);
+  drop_forget(di);
 }
 
 void deinit_lp_real_f32(struct demod_state *fm) {   /* src/rtl_fm_player.c:455-470 */
@@ -1120,14 +1148,14 @@ void deinit_lp_real_f32(struct demod_state *fm) {   /* src/rtl_fm_player.c:455-4
 
 void rotate_90_u8_f32(struct demod_state *d) {   /* src/rtl_fm_player.c:206-226 */
   struct drop_in *di = drop_find(d, 1);
-  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("rotate_90_u8_f32"); }
+  if (!di) { fail(FMD_E_NOMEM, "out of host memory"); DIE(d, "rotate_90_u8_f32"); }
   di->convert_mode = 0;
   d->lp_len = (int)d->buf_len;
 }
 
 void u8_f32(struct demod_state *d) {             /* src/rtl_fm_player.c:228-239 */
   struct drop_in *di = drop_find(d, 1);
-  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("u8_f32"); }
+  if (!di) { fail(FMD_E_NOMEM, "out of host memory"); DIE(d, "u8_f32"); }
   di->convert_mode = 1;
   d->lp_len = (int)d->buf_len;
 }
@@ -1142,8 +1170,8 @@ static void linear_to_ring(const float *lin, int size, int pos, float *ring) {
 
 void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 */
   struct drop_in *di = drop_find(d, 1);
-  if (!di) { fail(FMD_E_NOMEM, "too many demod_state objects"); die("full_demod"); }
-  if (!d->lpr.br || !d->lpr.fm) { fail(FMD_E_STATE, "init_lp_real_f32 was not called"); die("full_demod"); }
+  if (!di) { fail(FMD_E_NOMEM, "out of host memory"); DIE(d, "full_demod"); }
+  if (!d->lpr.br || !d->lpr.fm) { fail(FMD_E_STATE, "init_lp_real_f32 was not called"); DIE(d, "full_demod"); }
   pthread_once(&g_dropin_once, dropin_read_env);
   const int math = g_dropin_math;
   fmd_config c = {d->rate_in, d->rate_out, d->rate_out2, d->lpr.mode, d->lpr.size, d->deemph != 0.0,
@@ -1159,7 +1187,7 @@ void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 
     memcpy(t.fs, d->lpr.fs, sizeof(float) * (size_t)(d->lpr.size >> 1));
     t.swf = d->lpr.swf;
     t.cwf = d->lpr.cwf;
-    if (fmd_batch_create(&di->batch, &c, &t, 1, -1)) die("full_demod: fmd_batch_create");
+    if (fmd_batch_create(&di->batch, &c, &t, 1, -1)) DIE(d, "full_demod: fmd_batch_create");
     di->cfg = c;
     /* a new batch starts from zeroed device state: what the struct holds (the stream so far - the reference keeps running across a
      * change of volume, buf_len, rates or de-emphasis, all of which are in fmd_config) must be uploaded whatever the shadow says */
@@ -1183,35 +1211,35 @@ void full_demod(struct demod_state *d) {         /* src/rtl_fm_player.c:758-788 
   ring_to_linear(d->lpr.bs, size, d->lpr.pos, st.bs);
   const int upload = !(di->shadow_valid && di->shadow_pos == d->lpr.pos && memcmp(&st, &di->shadow, sizeof(st)) == 0);
 
-  if (hipSetDevice(b->device) != hipSuccess) { fail(FMD_E_HIP, "hipSetDevice failed"); die("full_demod"); }
-  if (ensure_staging(b, 1)) die("full_demod: staging");
+  if (hipSetDevice(b->device) != hipSuccess) { fail(FMD_E_HIP, "hipSetDevice failed"); DIE(d, "full_demod"); }
+  if (ensure_staging(b, 1)) DIE(d, "full_demod: staging");
   if (!di->pin || di->pin_pcm < (size_t)b->pcm_stride) {
     if (di->pin) hipHostFree(di->pin);
     di->pin = NULL;
     if (hipHostMalloc((void **)&di->pin, sizeof(*di->pin) + sizeof(int16_t) * (size_t)b->pcm_stride, hipHostMallocDefault) != hipSuccess) {
       fail(FMD_E_NOMEM, "pinned staging for the drop-in surface");
-      die("full_demod");
+      DIE(d, "full_demod");
     }
     di->pin_pcm = (size_t)b->pcm_stride;
   }
   hipError_t e = hipSuccess;
   if (upload) {
     /* (a caller-edited state, or the first block: everything queued on the batch's own stream, in order) */
-    if (batch_quiesce(b) != hipSuccess) { fail(FMD_E_HIP, "device busy"); die("full_demod"); }
+    if (batch_quiesce(b) != hipSuccess) { fail(FMD_E_HIP, "device busy"); DIE(d, "full_demod"); }
     di->pin->st = st;
     e = hipMemcpyAsync(b->d_state[b->cur], &di->pin->st, sizeof(st), hipMemcpyHostToDevice, b->stream);
-    if (e != hipSuccess) { fail(FMD_E_HIP, "state upload: %s", hipGetErrorString(e)); die("full_demod"); }
-    if (hipStreamSynchronize(b->stream) != hipSuccess) { fail(FMD_E_HIP, "state upload"); die("full_demod"); }   /* pin->st is reused below */
+    if (e != hipSuccess) { fail(FMD_E_HIP, "state upload: %s", hipGetErrorString(e)); DIE(d, "full_demod"); }
+    if (hipStreamSynchronize(b->stream) != hipSuccess) { fail(FMD_E_HIP, "state upload"); DIE(d, "full_demod"); }   /* pin->st is reused below */
   }
   e = hipMemcpyAsync(b->d_iq, d->buf, (size_t)d->buf_len, hipMemcpyHostToDevice, b->stream);
-  if (e != hipSuccess) { fail(FMD_E_HIP, "IQ upload: %s", hipGetErrorString(e)); die("full_demod"); }
-  if (fmd_batch_run_device(b, b->d_iq, 1, b->d_pcm, b->d_lens, NULL)) die("full_demod: run");
+  if (e != hipSuccess) { fail(FMD_E_HIP, "IQ upload: %s", hipGetErrorString(e)); DIE(d, "full_demod"); }
+  if (fmd_batch_run_device(b, b->d_iq, 1, b->d_pcm, b->d_lens, NULL)) DIE(d, "full_demod: run");
   if ((e = hipMemcpyAsync(di->pin->pcm, b->d_pcm, sizeof(int16_t) * (size_t)b->pcm_stride, hipMemcpyDeviceToHost, b->stream)) != hipSuccess ||
       (e = hipMemcpyAsync(&di->pin->len, b->d_lens, sizeof(int32_t), hipMemcpyDeviceToHost, b->stream)) != hipSuccess ||
       (e = hipMemcpyAsync(&di->pin->st, b->d_state[b->cur], sizeof(st), hipMemcpyDeviceToHost, b->stream)) != hipSuccess ||
       (e = hipStreamSynchronize(b->stream)) != hipSuccess) {                       /* the one wait of the block */
     fail(FMD_E_HIP, "full_demod: %s", hipGetErrorString(e));
-    die("full_demod");
+    DIE(d, "full_demod");
   }
   const int32_t len = di->pin->len;
   memcpy(d->result, di->pin->pcm, sizeof(int16_t) * (size_t)(len > 0 ? len : 0));

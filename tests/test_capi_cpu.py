@@ -183,6 +183,40 @@ def test_create_without_device_fails_loudly():
         R.BatchDemod(R.wbfm_config(), 1)
 
 
+def test_dropin_failure_reaches_the_callers_handler_instead_of_abort():
+    """The reference-shaped calls are void: by default a failure inside them abort()s (a demodulator that silently stops is the worse failure for the
+    program this drops into).  With fmd_dropin_set_error_handler installed the call reports (which call, fmd_last_error's text) and returns with
+    result_len = 0 - here: full_demod without a HIP device.  Also: more than 64 structs may be registered (the registry grows), and
+    fmd_dropin_set_math takes the family the environment variable would otherwise choose."""
+    if R.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    L = R.lib()
+    seen = []
+    cb = capi.DROPIN_ERROR_CB(lambda where, msg, ctx: seen.append((where.decode(), msg.decode())))
+    L.fmd_dropin_set_error_handler(cb, None)
+    try:
+        assert L.fmd_dropin_set_math(R.MATH_FAST) == 0 and L.fmd_dropin_set_math(99) < 0
+        states = [capi.DemodState() for _ in range(70)]           # 1.8 MB each
+        for d in states:
+            L.demod_init(C.byref(d))
+            d.rate_in, d.rate_out, d.rate_out2 = 300000, 300000, 48000
+            d.lpr.mode, d.lpr.size = 2, 90
+            d.deemph_lambda, d.volume, d.buf_len = 0.6592406, 0.4, 262144
+            L.rotate_90_u8_f32(C.byref(d))                        # registers the struct: the 65th too
+        d = states[-1]
+        L.init_lp_real_f32(C.byref(d))
+        d.result_len = 12345
+        L.full_demod(C.byref(d))
+        assert d.result_len == 0
+        assert seen and seen[-1][0].startswith("full_demod") and "no HIP device" in seen[-1][1], seen
+        L.deinit_lp_real_f32(C.byref(d))
+        for d in states:
+            L.fmd_demod_release(C.byref(d))
+    finally:
+        L.fmd_dropin_set_error_handler(capi.DROPIN_ERROR_CB(0), None)
+        L.fmd_dropin_set_math(R.MATH_EXACT)
+
+
 def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "_LIB", str(tmp_path / "nope.so"))
