@@ -131,3 +131,28 @@ def test_stage_d_stays_on_the_vector_alu_where_its_error_estimate_is_too_large(R
             want = R.MATH_FAST_MFMA if (name == "stereo_300k" and vol == 8.0) else R.MATH_FAST_MFMA_F
             assert b.math == want, (name, vol, b.math)
             b.close()
+
+
+@pytest.mark.parametrize("name", ["nfm_25k", "mono_300k", "stereo_300k"])
+def test_parity_where_the_origin_threshold_is_clamped(R, name):
+    """fmdk_params.org_thr grows with coef x (largest tap behind the discriminator) / 7600 and is clamped at 200 x 1e-3 - reached by narrow FM from
+    volume 80.  Volume 100 on a weak signal (a 20-LSB carrier in +-2 LSB of noise: most tiles then run stages A and B in the reference's arithmetic) and on
+    noise: every +-1 LSB family within 1 LSB of the oracle, the exact kernels bit-identical.  (What it costs: profiles/r6l_high_volume_time.txt.)"""
+    from oracle import OracleStream, lcg_bytes
+    kw, NB = CONFIGS[name], 3
+    rng = np.random.default_rng(11)
+    n = NB * BL // 2
+    ph = 2 * np.pi * (-0.25) * np.arange(n) + 0.3 * np.sin(2 * np.pi * 1e-4 * np.arange(n))
+    weak = np.empty(2 * n, dtype=np.uint8)
+    weak[0::2] = np.clip(np.round(127.5 + 20.0 * np.cos(ph) + rng.normal(0, 2.0, n)), 0, 255)
+    weak[1::2] = np.clip(np.round(127.5 + 20.0 * np.sin(ph) + rng.normal(0, 2.0, n)), 0, 255)
+    iq = np.stack([weak, lcg_bytes(NB * BL, 4321)[0]]).reshape(2, NB, BL)
+    want = [OracleStream(volume=100.0, **kw).run(iq[s].reshape(-1), BL) for s in range(2)]
+    for math, tol in [(R.MATH_EXACT, 0)] + [(m, 1) for m in R.FAST_MATHS]:
+        b = R.BatchDemod(R.wbfm_config(block_len=BL, math=math, volume=100.0, **kw), 2)
+        got, lens = b.run_host_concat(iq, NB)
+        for s in range(2):
+            assert np.array_equal(lens[s], want[s][1])
+            d = int(np.abs(got[s].astype(np.int32) - want[s][0].astype(np.int32)).max())
+            assert d <= tol, (name, math, s, d)
+        b.close()
