@@ -147,7 +147,11 @@ void u8_f32(struct demod_state *d);                 /* :228 */
 void full_demod(struct demod_state *d);             /* :758 */
 /* Additive: release the device resources full_demod attached to *d. */
 void fmd_demod_release(struct demod_state *d);
-/* Additive: what the void calls above cannot say through their signatures.
+
+#endif /* FMD_NO_REFERENCE_TYPES */
+
+/* Additive (declared whether or not FMD_NO_REFERENCE_TYPES is defined: a program that keeps its own struct definitions calls these too): what the void
+ * reference-shaped calls cannot say through their signatures.
  *   fmd_dropin_set_math: the arithmetic family of the calls above (an fmd_config.math value), instead of the FMD_MATH_FAST environment variable; call it
  *     before the first full_demod (a struct's batch is rebuilt when the family changes).
  *   fmd_dropin_set_error_handler: by default a failure inside one of the calls above (no device, out of memory, a HIP error) prints a line and abort()s; with
@@ -155,7 +159,7 @@ void fmd_demod_release(struct demod_state *d);
 int fmd_dropin_set_math(int math);
 typedef void (*fmd_dropin_error_fn)(const char *where, const char *message, void *ctx);
 void fmd_dropin_set_error_handler(fmd_dropin_error_fn fn, void *ctx);
-#endif /* FMD_NO_REFERENCE_TYPES */
+
 
 /* ------------------------------------------------------------------------
  * 2. Batch API: n_streams independent demodulators, many blocks per launch
